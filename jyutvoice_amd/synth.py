@@ -1,0 +1,153 @@
+"""Synthetic weights and inputs (there are no checkpoints or datasets on the build/GPU boxes).
+
+Weights are *key-hashed*: every tensor is drawn from a generator seeded with crc32(key), so the
+same values can be produced anywhere (the survey container applied the same recipe to the
+reference's own modules to make tests/golden/*.npz) without shipping a checkpoint.
+
+Recipe, chosen so a 70-block random network stays numerically tame:
+  matrices / conv kernels   N(0,1) * fan_in^-1/2
+  biases, LayerNorm betas   N(0,1) * 0.02
+  LayerNorm gains           1 + 0.1 N(0,1)
+  Snake alpha               1 + 0.1 |N(0,1)|
+  weight-norm g             ||v||_row * (1 + 0.1 N(0,1))      (so the fold w = g v/||v|| is exercised)
+  f0 classifier             weight * 60, bias 80  -> f0 mostly 20..250 Hz with a few unvoiced frames
+  conv_post                 weight * 0.3                       (keeps exp(.) in iSTFT range)
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from typing import Dict, Optional
+
+import torch
+
+from . import spec
+
+
+def _gen(key: str) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed(zlib.crc32(key.encode("utf-8")))
+    return g
+
+
+def _randn(key: str, shape) -> torch.Tensor:
+    return torch.randn(tuple(shape), generator=_gen(key), dtype=torch.float32)
+
+
+_GAIN_SUFFIX = (".gamma", "block.2.weight", "norm1.weight", "norm3.weight")
+_WN_G = (".parametrizations.weight.original0", ".weight_g")
+_WN_V = (".parametrizations.weight.original1", ".weight_v")
+
+
+def _fan_in(key: str, shape) -> float:
+    if key.startswith("ups."):
+        i = int(key.split(".")[1])
+        return shape[0] * shape[2] / spec.HIFT_UP_RATES[i]
+    if "emb" in key.split(".")[-2] or key.endswith("syllable_pos.weight"):
+        return float(shape[1])
+    f = 1
+    for s in shape[1:]:
+        f *= s
+    return float(f)
+
+
+def _one(key: str, shape, inv) -> torch.Tensor:
+    if key.endswith(".alpha"):
+        return 1.0 + 0.1 * _randn(key, shape).abs()
+    if key.endswith(_GAIN_SUFFIX):
+        return 1.0 + 0.1 * _randn(key, shape)
+    if key.endswith(_WN_G):
+        for gs, vs in zip(_WN_G, _WN_V):
+            if key.endswith(gs):
+                vkey = key[: -len(gs)] + vs
+        v = _one(vkey, inv[vkey], inv)
+        norm = v.flatten(1).norm(dim=1).view(shape)
+        return norm * (1.0 + 0.1 * _randn(key, shape))
+    if key.endswith((".bias", ".beta")):
+        b = 0.02 * _randn(key, shape)
+        if key == "f0_predictor.classifier.bias":
+            b = b + 80.0
+        return b
+    w = _randn(key, shape) * (_fan_in(key, shape) ** -0.5)
+    if key == "f0_predictor.classifier.weight":
+        w = w * 60.0
+    if key.startswith("conv_post."):
+        w = w * 0.3
+    return w
+
+
+def synth_state_dict(inventory, prefix: str = "") -> Dict[str, torch.Tensor]:
+    """Synthetic fp32 CPU state-dict for `inventory` (spec.TTS_INVENTORY or spec.HIFT_INVENTORY).
+
+    `prefix` filters keys (e.g. "decoder.estimator.")."""
+    out = {}
+    for key, shape in inventory.items():
+        if key.startswith(prefix):
+            out[key] = _one(key, shape, inventory).contiguous()
+    return out
+
+
+def tts_state_dict(fixed_duration: Optional[float] = None) -> Dict[str, torch.Tensor]:
+    """Synthetic JyutVoiceTTS state-dict.  `fixed_duration` (e.g. 1.5) forces every token to
+    ceil(fixed_duration) frames by zeroing dp.proj.weight (fixed-length batches)."""
+    sd = synth_state_dict(spec.TTS_INVENTORY)
+    if fixed_duration is not None:
+        sd["dp.proj.weight"] = torch.zeros_like(sd["dp.proj.weight"])
+        sd["dp.proj.bias"] = torch.full_like(sd["dp.proj.bias"], math.log(fixed_duration))
+    return sd
+
+
+def hift_state_dict() -> Dict[str, torch.Tensor]:
+    return synth_state_dict(spec.HIFT_INVENTORY)
+
+
+def rand_noise() -> torch.Tensor:
+    """The CFM's fixed noise tensor: torch.manual_seed(0); torch.randn([1,80,15000]) on the CPU
+    generator (jyutvoice/flow/flow_matching.py:353-354).  A private generator with seed 0 yields
+    the same stream as the global one without touching global RNG state (unlike the reference)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(0)
+    return torch.randn([1, spec.N_FEATS, spec.NOISE_FRAMES], generator=g, dtype=torch.float32)
+
+
+def utterance(index: int, n_tokens: int):
+    """One synthetic utterance: five equal-length id lists with blanks interspersed and pad 0 at
+    both ends (the contract of jyutvoice/text/__init__.py:20-35 + utils/utils.py:131-135), and a
+    N(0,1) speaker embedding."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(1234 + index)
+    n_real = (n_tokens - 1) // 2
+    def ids(hi):
+        real = torch.randint(1, hi, (n_real,), generator=g)
+        out = torch.zeros(n_tokens, dtype=torch.int64)
+        out[1 : 2 * n_real : 2] = real
+        return out
+    phone = ids(spec.ENC_N_VOCAB)
+    lang = ids(spec.ENC_N_LANG)
+    tone = ids(spec.ENC_N_TONE)
+    word_pos = ids(spec.ENC_N_WORD_POS)
+    syl_pos = ids(spec.ENC_N_SYL_POS)
+    spk = torch.randn(spec.SPK_EMBED_DIM, generator=g, dtype=torch.float32)
+    return phone, lang, tone, word_pos, syl_pos, spk
+
+
+def batch(n_utts: int, n_tokens: int, first_index: int = 0, lengths=None):
+    """Padded batch of synthetic utterances -> dict of tensors shaped like synthesise()'s inputs."""
+    cols = [utterance(first_index + i, n_tokens) for i in range(n_utts)]
+    x = torch.stack([c[0] for c in cols])
+    out = {
+        "x": x,
+        "lang": torch.stack([c[1] for c in cols]),
+        "tone": torch.stack([c[2] for c in cols]),
+        "word_pos": torch.stack([c[3] for c in cols]),
+        "syllable_pos": torch.stack([c[4] for c in cols]),
+        "spk_embed": torch.stack([c[5] for c in cols]),
+    }
+    if lengths is None:
+        lengths = [n_tokens] * n_utts
+    xl = torch.tensor(lengths, dtype=torch.int64)
+    for k in ("x", "lang", "tone", "word_pos", "syllable_pos"):
+        pad = torch.arange(n_tokens).unsqueeze(0) >= xl.unsqueeze(1)
+        out[k] = out[k].masked_fill(pad, 0)
+    out["x_lengths"] = xl
+    return out
