@@ -1,0 +1,122 @@
+/* libjyutvoice_hip.so -- C ABI of the MI355X-native JyutVoice synthesis hot path.
+ *
+ * Plain C: opaque context, raw pointers, explicit shapes, a HIP stream passed as void*.  No torch
+ * types, no exceptions across the boundary: every call returns JV_OK (0) or an error code and
+ * jv_last_error() returns the message.  All work is enqueued on the caller's stream; device
+ * pointers are caller-owned unless stated.  The library owns only its context: packed weights and a
+ * workspace sized at jv_create().
+ *
+ * Each entry point names the reference interface it stands in for (paths relative to the
+ * indiejoseph/JyutVoice tree).  The precedent for a raw-pointer estimator seam in the reference is the
+ * TensorRT path of ConditionalCFM.forward_estimator (jyutvoice/flow/flow_matching.py:267-297), which
+ * hands data_ptr()s of x/mask/mu/t/spks/cond to an engine and reads the result from x.
+ *
+ * Tensor layouts at this boundary are the reference's own: channels-first fp32, e.g. mel [B,80,T].
+ */
+#ifndef JYUTVOICE_HIP_H
+#define JYUTVOICE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JV_OK 0
+#define JV_ERR_ARG 1    /* bad argument                                   */
+#define JV_ERR_STATE 2  /* weights missing / not finalized                */
+#define JV_ERR_HIP 3    /* a HIP runtime call failed                      */
+#define JV_ERR_SHAPE 4  /* shape mismatch or capacity exceeded            */
+#define JV_ERR_NAME 5   /* unknown tensor name                            */
+
+#define JV_MODEL_TTS 0  /* JyutVoiceTTS state-dict: encoder.*, dp.*, decoder.estimator.*, spk_embed_affine_layer.* */
+#define JV_MODEL_HIFT 1 /* HiFTGenerator state-dict                                                                */
+
+typedef struct jv_context jv_context;
+
+/* ---- lifetime -------------------------------------------------------------------------------------
+ * Replaces the object graph configs/base.yaml:26-110 builds (JyutVoiceTTS + HiFTGenerator).  Capacity:
+ * at most max_batch utterances of max_frames mel frames / max_tokens text tokens per call. */
+int jv_create(jv_context** out, int device, int max_batch, int max_frames, int max_tokens);
+void jv_destroy(jv_context* ctx);
+/* message of the last failing call on this thread (valid until the next failure) */
+const char* jv_last_error(void);
+
+/* ---- weights ---------------------------------------------------------------------------------------
+ * Replaces tts.load_state_dict(ckpt["state_dict"]) / hift.load_state_dict(torch.load(hift.pt))
+ * (infer.py:343-351).  Names and shapes are the checkpoint's own keys; the registry is enumerable so
+ * a loader can validate a checkpoint before touching the GPU. */
+int jv_num_tensors(const jv_context* ctx);
+const char* jv_tensor_name(const jv_context* ctx, int i);
+int jv_tensor_model(const jv_context* ctx, int i);
+int jv_tensor_ndim(const jv_context* ctx, int i);
+int64_t jv_tensor_dim(const jv_context* ctx, int i, int d);
+/* copy one fp32 tensor (host or device memory) into the context */
+int jv_load_tensor(jv_context* ctx, const char* name, const float* data, const int64_t* shape, int ndim, int on_device,
+                   void* stream);
+/* the CFM's fixed noise tensor [1,80,15000] (CausalConditionalCFM.rand_noise, flow_matching.py:353-354: a plain
+ * attribute, not a state-dict entry; the host regenerates it from torch seed 0) */
+int jv_load_noise(jv_context* ctx, const float* data, int64_t numel, int on_device, void* stream);
+/* all tensors of `model` present -> fold weight-norm, pack GEMM operands.  Errors name the missing key. */
+int jv_finalize(jv_context* ctx, int model, void* stream);
+
+/* ---- flow decoder ------------------------------------------------------------------------------------
+ * jv_flow_estimator_step: CausalConditionalDecoder.forward (jyutvoice/flow/decoder.py:917-1018) through the
+ * forward_estimator seam (flow_matching.py:267-297).  x, mu, cond, out: [B2,80,T]; t: [B2]; spks: [B2,80];
+ * lens: [B2] int32 valid frames per row (NULL = all T), the key-padding mask of decoder.py:951-959.
+ * out may alias x (the TRT seam writes its result into x). */
+int jv_flow_estimator_step(jv_context* ctx, const float* x, const int32_t* lens, const float* mu, const float* t,
+                           const float* spks, const float* cond, int B2, int T, float* out, void* stream);
+/* jv_cfm_solve: CausalConditionalCFM.forward + ConditionalCFM.solve_euler (flow_matching.py:356-401, 215-265):
+ * fixed noise prefix * temperature, cosine schedule, n_timesteps Euler steps with CFG rate 0.7.
+ * mu, cond, mel: [B,80,T]; spks: [B,80]; lens: [B] int32 or NULL.  t_span_host: optional n_timesteps+1 host floats
+ * (the caller's own 1-cos(linspace*pi/2)); NULL = computed here.  B > 1 is the batched extension, defined as the
+ * per-utterance loop of the batch-1-only reference. */
+int jv_cfm_solve(jv_context* ctx, const float* mu, const int32_t* lens, const float* spks, const float* cond, int B, int T,
+                 int n_timesteps, float temperature, const float* t_span_host, float* mel, void* stream);
+
+/* ---- text encoder + duration predictor + length regulation ---------------------------------------------
+ * jv_encoder_fwd: spk_embed_affine_layer(normalize(spk)) + TextEncoder.forward + DurationPredictor.forward
+ * (jyutvoice/models/jyutvoice_tts.py:175-182, text_encoder.py:406-451, duration_predictor.py:48-60).
+ * ids: int64 [B,Tt] each; x_lengths: int64 [B]; spk: [B,192] (raw, un-normalised).
+ * outputs: x [B,576,Tt], mu_x [B,80,Tt], logw [B,1,Tt], spks_proj [B,80]. */
+int jv_encoder_fwd(jv_context* ctx, const int64_t* phone, const int64_t* lang, const int64_t* tone, const int64_t* word_pos,
+                   const int64_t* syllable_pos, const int64_t* x_lengths, const float* spk, int B, int Tt, float* x,
+                   float* mu_x, float* logw, float* spks_proj, void* stream);
+/* jv_length_regulate: w_ceil = ceil(exp(logw)*mask)*length_scale, y_lengths, generate_path, mu_y = attn^T mu_x
+ * (jyutvoice_tts.py:184-203, utils/model.py:29-46).  Two-phase because T_max is data dependent:
+ *   phase 1 (attn == NULL): writes w_ceil [B,1,Tt] and y_lengths [B] int64 (device); the caller reads max(y_lengths)
+ *   phase 2: writes attn [B,Tt,Ty] (dense 0/1 path) and mu_y [B,80,Ty] for the given Ty. */
+int jv_length_regulate(jv_context* ctx, const float* logw, const int64_t* x_lengths, const float* mu_x, int B, int Tt,
+                       float length_scale, float* w_ceil, int64_t* y_lengths, int Ty, float* attn, float* mu_y,
+                       void* stream);
+
+/* ---- HiFT vocoder -------------------------------------------------------------------------------------------
+ * jv_hift_f0:     ConvRNNF0Predictor.forward (jyutvoice/hifigan/f0_predictor.py:52-55): mel [B,80,T] -> f0 [B,T]
+ * jv_hift_source: f0_upsamp + SourceModuleHnNSF/SineGen (generator.py:459-461, 141-176, 220-236) with the random
+ *                 draws supplied: phase [B,9] (harmonic 0 ignored, treated as 0), noise [B,9,480T] ~ N(0,1);
+ *                 -> s [B,1,480T]
+ * jv_hift_decode: HiFTGenerator.decode (generator.py:396-432): mel [B,80,T], s [B,1,480T] -> wav [B,480T]
+ * lens: [B] int32 valid mel frames per utterance or NULL. */
+int jv_hift_f0(jv_context* ctx, const float* mel, const int32_t* lens, int B, int T, float* f0, void* stream);
+int jv_hift_source(jv_context* ctx, const float* f0, const float* phase, const float* noise, int B, int T, float* s,
+                   void* stream);
+int jv_hift_decode(jv_context* ctx, const float* mel, const float* s, const int32_t* lens, int B, int T, float* wav,
+                   void* stream);
+
+/* ---- operator-level entry points (used by the parity tests; same kernels the stages above launch) -------------
+ * jv_op_conv_gemm: out[m,n] = act(sum_{j,ci} A[m + tap_row0 + j*dil, ci] * W[n, j*Cin + ci] + bias[n]) (+ res[m,n])
+ *                  A [a_rows, Cin] rows, W [N, ntaps*Cin], optional LayerNorm over N (N == 256) before act.
+ * jv_op_attention: softmax(q k^T / 8 over keys < lens[b]) v for qkv rows [G + b*S + t][1536], 8 heads x 64.
+ * jv_op_layernorm: rows [rows, C]. */
+int jv_op_conv_gemm(const float* A, int64_t a_rows, int M, int Cin, int ntaps, int tap_row0, int dil, const float* W, int N,
+                    const float* bias, int act, int prologue, const float* alpha, float slope, const float* ln_g,
+                    const float* ln_b, float ln_eps, const uint8_t* rowmask, const float* res, float* out, void* stream);
+int jv_op_attention(const float* qkv, const int32_t* lens, int B, int G, int S, int L, float* out, void* stream);
+int jv_op_layernorm(const float* x, const float* g, const float* b, float eps, int64_t rows, int C, float* out,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JYUTVOICE_HIP_H */

@@ -1,0 +1,66 @@
+"""Build libjyutvoice_hip.so in-tree with hipcc for gfx950 (no torch involved: the library is plain HIP/C++).
+
+    python -m jyutvoice_amd.build [--force]
+
+Objects are cached per source in jyutvoice_amd/csrc/build/ keyed by mtime of the source and headers.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libjyutvoice_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libjyutvoice_hip.so cannot be built (ROCm toolchain required)")
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    jobs = []
+    objs = []
+    for s in srcs:
+        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), newest_hdr):
+            jobs.append((s, o))
+
+    def cc(job):
+        s, o = job
+        r = subprocess.run([hipcc, *FLAGS, "-c", s, "-o", o], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{r.stdout}\n{r.stderr}")
+        return s
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            for s in ex.map(cc, jobs):
+                if verbose:
+                    print(f"[jyutvoice_amd.build] compiled {os.path.basename(s)}", flush=True)
+    if jobs or force or not os.path.exists(LIB):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[jyutvoice_amd.build] linked {LIB}", flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

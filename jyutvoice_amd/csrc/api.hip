@@ -1,0 +1,209 @@
+// extern "C" surface of libjyutvoice_hip.so (include/jyutvoice_hip.h).  Nothing throws across it.
+#include <string.h>
+
+#include <new>
+
+#include "../../include/jyutvoice_hip.h"
+#include "jv_model.h"
+#include "jv_ops.h"
+
+namespace jv {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+int ws_alloc(Context& c, size_t bytes, void** out) {
+  void* p = nullptr;
+  bytes = (bytes + 255) & ~(size_t)255;
+  JV_HIP(hipMalloc(&p, bytes));
+  JV_HIP(hipMemset(p, 0, bytes));
+  c.ws_allocs.push_back(p);
+  *out = p;
+  return JV_OK;
+}
+
+int hift_ws_create(Context& c);   // hift.hip
+int enc_ws_create(Context& c);    // encoder.hip
+void flow_ws_destroy(Context& c);
+void hift_ws_destroy(Context& c);
+void enc_ws_destroy(Context& c);
+
+}  // namespace jv
+
+using jv::Context;
+
+struct jv_context {
+  Context c;
+};
+
+#define CTX_GUARD(ctx)                                                       \
+  if (!(ctx)) return jv::fail(JV_ERR_ARG, "null context");                   \
+  {                                                                          \
+    hipError_t _e = hipSetDevice((ctx)->c.device);                           \
+    if (_e != hipSuccess) return jv::fail(JV_ERR_HIP, hipGetErrorString(_e)); \
+  }
+
+extern "C" {
+
+const char* jv_last_error(void) { return jv::g_last_error.c_str(); }
+
+int jv_create(jv_context** out, int device, int max_batch, int max_frames, int max_tokens) {
+  if (!out) return jv::fail(JV_ERR_ARG, "jv_create: null out pointer");
+  *out = nullptr;
+  if (max_batch < 1 || max_frames < 1 || max_tokens < 1) return jv::fail(JV_ERR_ARG, "jv_create: capacities must be >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return jv::fail(JV_ERR_HIP, "jv_create: no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return jv::fail(JV_ERR_ARG, "jv_create: bad device index");
+  JV_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  JV_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return jv::fail(JV_ERR_HIP, std::string("jv_create: built for gfx950 only, found ") + prop.gcnArchName);
+  jv_context* ctx = new (std::nothrow) jv_context();
+  if (!ctx) return jv::fail(JV_ERR_HIP, "jv_create: out of host memory");
+  Context& c = ctx->c;
+  c.device = device;
+  c.max_batch = max_batch;
+  c.max_frames = max_frames;
+  c.max_tokens = max_tokens;
+  jv::build_registry(c);
+  int rc = jv::conv_gemm_init();
+  if (rc == JV_OK) rc = jv::flow_ws_create(c);
+  if (rc == JV_OK) rc = jv::hift_ws_create(c);
+  if (rc == JV_OK) rc = jv::enc_ws_create(c);
+  if (rc == JV_OK) rc = jv::ws_alloc(c, sizeof(float) * jv::N_FEATS * jv::NOISE_FRAMES, reinterpret_cast<void**>(&c.noise));
+  if (rc != JV_OK) {
+    jv_destroy(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return JV_OK;
+}
+
+void jv_destroy(jv_context* ctx) {
+  if (!ctx) return;
+  Context& c = ctx->c;
+  (void)hipSetDevice(c.device);
+  (void)hipDeviceSynchronize();
+  for (void* p : c.ws_allocs) (void)hipFree(p);
+  c.raw_arena.release();
+  c.packed.release();
+  jv::flow_ws_destroy(c);
+  jv::hift_ws_destroy(c);
+  jv::enc_ws_destroy(c);
+  delete ctx;
+}
+
+int jv_num_tensors(const jv_context* ctx) { return ctx ? (int)ctx->c.raw.size() : 0; }
+const char* jv_tensor_name(const jv_context* ctx, int i) {
+  return (ctx && i >= 0 && i < (int)ctx->c.raw.size()) ? ctx->c.raw[i].name.c_str() : nullptr;
+}
+int jv_tensor_model(const jv_context* ctx, int i) {
+  return (ctx && i >= 0 && i < (int)ctx->c.raw.size()) ? ctx->c.raw[i].model : -1;
+}
+int jv_tensor_ndim(const jv_context* ctx, int i) {
+  return (ctx && i >= 0 && i < (int)ctx->c.raw.size()) ? (int)ctx->c.raw[i].shape.size() : -1;
+}
+int64_t jv_tensor_dim(const jv_context* ctx, int i, int d) {
+  if (!ctx || i < 0 || i >= (int)ctx->c.raw.size()) return -1;
+  const auto& s = ctx->c.raw[i].shape;
+  return (d >= 0 && d < (int)s.size()) ? s[d] : -1;
+}
+
+int jv_load_tensor(jv_context* ctx, const char* name, const float* data, const int64_t* shape, int ndim, int on_device,
+                   void* stream) {
+  CTX_GUARD(ctx);
+  if (!name || !data || !shape) return jv::fail(JV_ERR_ARG, "jv_load_tensor: null argument");
+  Context& c = ctx->c;
+  auto it = c.index.find(name);
+  if (it == c.index.end()) return jv::fail(JV_ERR_NAME, std::string("unexpected key: ") + name);
+  jv::RawTensor& t = c.raw[it->second];
+  bool same = ndim == (int)t.shape.size();
+  for (int d = 0; same && d < ndim; ++d) same = shape[d] == t.shape[d];
+  if (!same) {
+    std::string want, got;
+    for (auto s : t.shape) want += std::to_string(s) + ",";
+    for (int d = 0; d < ndim; ++d) got += std::to_string(shape[d]) + ",";
+    return jv::fail(JV_ERR_SHAPE, std::string("size mismatch for ") + name + ": expected [" + want + "] got [" + got + "]");
+  }
+  if (c.ready[t.model]) return jv::fail(JV_ERR_STATE, "model already finalized; create a new context to reload");
+  if (!t.dev) JV_TRY(c.raw_arena.alloc((size_t)t.numel, &t.dev));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  JV_HIP(hipMemcpyAsync(t.dev, data, sizeof(float) * t.numel, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  if (!on_device) JV_HIP(hipStreamSynchronize(st));
+  t.loaded = true;
+  return JV_OK;
+}
+
+int jv_load_noise(jv_context* ctx, const float* data, int64_t numel, int on_device, void* stream) {
+  CTX_GUARD(ctx);
+  if (!data || numel != (int64_t)jv::N_FEATS * jv::NOISE_FRAMES)
+    return jv::fail(JV_ERR_SHAPE, "jv_load_noise: expected 80*15000 floats");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  JV_HIP(hipMemcpyAsync(ctx->c.noise, data, sizeof(float) * numel, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                        st));
+  if (!on_device) JV_HIP(hipStreamSynchronize(st));
+  ctx->c.noise_loaded = true;
+  return JV_OK;
+}
+
+int jv_finalize(jv_context* ctx, int model, void* stream) {
+  CTX_GUARD(ctx);
+  if (model != JV_MODEL_TTS && model != JV_MODEL_HIFT) return jv::fail(JV_ERR_ARG, "jv_finalize: unknown model id");
+  if (ctx->c.ready[model]) return JV_OK;
+  return jv::finalize_model(ctx->c, model, static_cast<hipStream_t>(stream));
+}
+
+int jv_flow_estimator_step(jv_context* ctx, const float* x, const int32_t* lens, const float* mu, const float* t,
+                           const float* spks, const float* cond, int B2, int T, float* out, void* stream) {
+  CTX_GUARD(ctx);
+  if (!x || !mu || !t || !spks || !cond || !out) return jv::fail(JV_ERR_ARG, "jv_flow_estimator_step: null tensor");
+  return jv::flow_estimator(ctx->c, x, lens, mu, t, spks, cond, B2, T, out, static_cast<hipStream_t>(stream));
+}
+
+int jv_cfm_solve(jv_context* ctx, const float* mu, const int32_t* lens, const float* spks, const float* cond, int B, int T,
+                 int n_timesteps, float temperature, const float* t_span_host, float* mel, void* stream) {
+  CTX_GUARD(ctx);
+  if (!mu || !spks || !cond || !mel) return jv::fail(JV_ERR_ARG, "jv_cfm_solve: null tensor");
+  return jv::cfm_solve(ctx->c, mu, lens, spks, cond, B, T, n_timesteps, temperature, t_span_host, mel,
+                       static_cast<hipStream_t>(stream));
+}
+
+// ---- operator-level entry points -------------------------------------------------------------------
+int jv_op_conv_gemm(const float* A, int64_t a_rows, int M, int Cin, int ntaps, int tap_row0, int dil, const float* W, int N,
+                    const float* bias, int act, int prologue, const float* alpha, float slope, const float* ln_g,
+                    const float* ln_b, float ln_eps, const uint8_t* rowmask, const float* res, float* out, void* stream) {
+  static bool inited = false;
+  if (!inited) {
+    JV_TRY(jv::conv_gemm_init());
+    inited = true;
+  }
+  jv::ConvGemmArgs a;
+  jv::conv_gemm_defaults(a);
+  a.A = A; a.lda = Cin; a.a_rows = a_rows; a.M = M; a.Cin = Cin; a.ntaps = ntaps; a.tap_row0 = tap_row0; a.tap_dil = dil;
+  a.W = W; a.ldw = ntaps * Cin; a.n_rows_w = N; a.N = N; a.bias = bias; a.out = out; a.ldo = N;
+  a.act = act; a.pro = prologue; a.pro_alpha = alpha; a.pro_slope = slope;
+  if (ln_g) { a.ln = 1; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = ln_eps; }
+  a.rowmask_in = rowmask; a.rowmask_out = rowmask;
+  a.res1 = res; a.ldr1 = N;
+  return jv::conv_gemm(a, 1, static_cast<hipStream_t>(stream));
+}
+
+int jv_op_attention(const float* qkv, const int32_t* lens, int B, int G, int S, int L, float* out, void* stream) {
+  jv::AttnArgs at;
+  at.qkv = qkv; at.ld = 1536; at.k_off = 512; at.v_off = 1024; at.out = out; at.ldo = 512;
+  at.B = B; at.H = 8; at.G = G; at.S = S; at.L = L; at.lens = lens;
+  return jv::attention64(at, static_cast<hipStream_t>(stream));
+}
+
+int jv_op_layernorm(const float* x, const float* g, const float* b, float eps, int64_t rows, int C, float* out, void* stream) {
+  return jv::layernorm_rows(x, nullptr, out, g, b, eps, rows, C, nullptr, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

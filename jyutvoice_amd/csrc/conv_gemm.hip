@@ -1,0 +1,403 @@
+// Implicit-GEMM 1-D convolution / linear layer on row buffers, fp32 in / fp32 accumulate on the
+// CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 fma chain, 64 FLOP/clk/SIMD).
+//
+//   out[m, n] = epilogue( sum_{j<ntaps} sum_{ci<Cin} pro(A[m + tap_row0 + j*tap_dil, ci]) * W[n, j*Cin + ci] )
+//
+// One kernel covers every contraction of the path except attention: Linear (ntaps=1), causal /
+// "same" / dilated Conv1d (a tap is a row offset in the row buffer), strided Conv1d (lda = stride*C,
+// Cin = k*C) and ConvTranspose1d (polyphase: N = stride*Cout, 3 taps, weights packed per phase).
+//
+// Tiling: 256 threads = 4 waves, each wave owns WM x WN outputs as (WM/32)x(WN/32) MFMA tiles.
+// Per K-chunk of 32 channels the A *window* (BM + (ntaps-1)*dil rows) is staged into LDS once --
+// with the prologue (mask select, Snake, LeakyReLU) applied on the way -- and reused by every tap;
+// the weight tile [BN][32] is staged per (tap, chunk).  Rows are 36 floats apart in LDS so the
+// ds_read_b128 operand fetches (16 rows of one k-quad per lane group) are bank-conflict free.
+// K order inside a chunk is permuted (lane half h owns k = 16h..16h+15) so one b128 read feeds four
+// MFMA steps; A and W use the same permutation, so the sum is unchanged.
+// Global->LDS staging is register-prefetched one step ahead (issue before the MFMAs, write after the
+// next barrier), so L2/HBM latency hides under the 64-cycle MFMAs.
+#include <math.h>
+
+#include <type_traits>
+
+#include "jv_common.h"
+
+namespace jv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LDS_STRIDE = 36;
+constexpr int LN_STRIDE = 260;
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    case ACT_MISH: return v * tanhf(log1pf(expf(v)));
+    case ACT_ELU: return v > 0.f ? v : expm1f(v);
+    case ACT_SILU: return v / (1.f + expf(-v));
+    default: return v;
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int NAMAX, bool LN, int PRO>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int MT = WM / 32, NT = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+  constexpr int NB = BN / 32;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int r32 = lane & 31, half = lane >> 5;
+  const int r8 = tid >> 3, c4 = tid & 7;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+  const float* A = p.A;
+  const float* W = p.W;
+  float* out = p.out;
+  if (gridDim.z > 1) {
+    const int z1 = blockIdx.z / p.nb2, z2 = blockIdx.z % p.nb2;
+    A += z1 * p.sA1 + z2 * p.sA2;
+    W += z1 * p.sW1 + z2 * p.sW2;
+    out += z1 * p.sO1 + z2 * p.sO2;
+  }
+
+  const int ntaps = p.ntaps, dil = p.tap_dil;
+  const int win = BM + (ntaps - 1) * dil;
+  const int na = (win + 31) >> 5;
+  float* ldsA = smem;
+  float* ldsW = smem + win * LDS_STRIDE;
+
+  // which of this thread's window rows exist and are unmasked (constant over the K loop)
+  unsigned avalid = 0;
+#pragma unroll
+  for (int i = 0; i < NAMAX; ++i) {
+    const int r = r8 + 32 * i;
+    const long ar = (long)m0 + p.tap_row0 + r;
+    bool ok = (i < na) && (r < win) && (ar >= 0) && (ar < p.a_rows);
+    if (ok && p.rowmask_in) ok = p.rowmask_in[ar] != 0;
+    avalid |= ok ? (1u << i) : 0u;
+  }
+
+  f32x4 pa[NAMAX];
+  f32x4 pw[NB];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  auto load_A = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < NAMAX; ++i) {
+      const long ar = (long)m0 + p.tap_row0 + r8 + 32 * i;
+      pa[i] = ((avalid >> i) & 1u) ? *reinterpret_cast<const f32x4*>(A + ar * p.lda + c0 + 4 * c4) : zero4;
+    }
+  };
+  auto load_W = [&](int j, int c0) {
+    const int kb = j * p.Cin + c0 + 4 * c4;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int n = n0 + r8 + 32 * i;
+      pw[i] = (n < p.n_rows_w) ? *reinterpret_cast<const f32x4*>(W + (long)n * p.ldw + kb) : zero4;
+    }
+  };
+  auto store_A = [&](int c0) {
+    f32x4 al = {1.f, 1.f, 1.f, 1.f};
+    if (PRO == PRO_SNAKE) al = *reinterpret_cast<const f32x4*>(p.pro_alpha + c0 + 4 * c4);
+#pragma unroll
+    for (int i = 0; i < NAMAX; ++i) {
+      const int r = r8 + 32 * i;
+      if (i < na && r < win) {
+        f32x4 v = pa[i];
+        if (PRO == PRO_SNAKE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float sn = sinf(v[e] * al[e]);
+            v[e] = v[e] + (1.0f / (al[e] + 1e-9f)) * (sn * sn);
+          }
+        } else if (PRO == PRO_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.pro_slope;
+        }
+        *reinterpret_cast<f32x4*>(ldsA + r * LDS_STRIDE + 4 * c4) = v;
+      }
+    }
+  };
+  auto store_W = [&]() {
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      *reinterpret_cast<f32x4*>(ldsW + (r8 + 32 * i) * LDS_STRIDE + 4 * c4) = pw[i];
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+
+  const int nchunks = p.Cin >> 5;
+  const int nsteps = nchunks * ntaps;
+  load_A(0);
+  load_W(0, 0);
+  int c = 0, j = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    __syncthreads();
+    if (j == 0) store_A(c * 32);
+    store_W();
+    __syncthreads();
+    int j2 = j + 1, c2 = c;
+    if (j2 == ntaps) { j2 = 0; c2 = c + 1; }
+    if (s + 1 < nsteps) {
+      if (j2 == 0) load_A(c2 * 32);
+      load_W(j2, c2 * 32);
+    }
+    const float* la = ldsA + (wm * WM + r32 + j * dil) * LDS_STRIDE + 16 * half;
+    const float* lw = ldsW + (wn * WN + r32) * LDS_STRIDE + 16 * half;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 a[MT], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(la + mt * 32 * LDS_STRIDE + 4 * q);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(lw + nt * 32 * LDS_STRIDE + 4 * q);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
+        }
+    }
+    j = j2;
+    c = c2;
+  }
+
+  // ---- epilogue: accumulators -> LDS (32 rows per pass) -> rolled, float4-coalesced finish -----------
+  if constexpr (!LN) {
+    constexpr int ES = WN + 4;                       // per-wave slab [32][WN+4]
+    float* slab = smem + wave * 32 * ES;
+    auto pass = [&](auto mt_tag) {
+      constexpr int mt = decltype(mt_tag)::value;
+      __syncthreads();
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          slab[((e & 3) + 8 * (e >> 2) + 4 * half) * ES + nt * 32 + r32] = acc[mt][nt][e];
+      __syncthreads();
+      constexpr int C4 = WN / 4;                     // float4 columns per row
+      constexpr int RPI = 64 / C4;                   // rows per iteration
+      const int col = (lane % C4) * 4, rsub = lane / C4;
+      const int n = n0 + wn * WN + col;
+#pragma unroll 1
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int row = it * RPI + rsub;
+        const int m = m0 + wm * WM + mt * 32 + row;
+        if (m >= p.M || n >= p.N) continue;
+        const float4 x = *reinterpret_cast<const float4*>(slab + row * ES + col);
+        float v[4] = {x.x, x.y, x.z, x.w};
+        const bool keep = !p.rowmask_out || p.rowmask_out[m];
+        const float* rv = p.rowvec ? p.rowvec + (long)p.row_sample[m] * p.rowvec_ld : nullptr;
+        float* o = out + (long)m * p.ldo + n;
+        const bool vec = (n + 3 < p.N) && !(p.ldo & 3) && (!p.res1 || !(p.ldr1 & 3)) && (!p.res2 || !(p.ldr2 & 3));
+        if (vec) {
+          float r1[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0};
+          if (p.res1) { const float4 t = *reinterpret_cast<const float4*>(p.res1 + (long)m * p.ldr1 + n); r1[0] = t.x; r1[1] = t.y; r1[2] = t.z; r1[3] = t.w; }
+          if (p.res2) { const float4 t = *reinterpret_cast<const float4*>(p.res2 + (long)m * p.ldr2 + n); r2[0] = t.x; r2[1] = t.y; r2[2] = t.z; r2[3] = t.w; }
+          if (p.accumulate) { const float4 t = *reinterpret_cast<const float4*>(o); pv[0] = t.x; pv[1] = t.y; pv[2] = t.z; pv[3] = t.w; }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = act_apply(v[e] + (p.bias ? p.bias[n + e] : 0.f), p.act);
+            if (!keep) t = 0.f;
+            if (rv) t += rv[n + e];
+            if (p.res1) t += r1[e];
+            if (p.res2) t += r2[e];
+            t *= p.out_scale;
+            if (p.accumulate) t += pv[e];
+            v[e] = t;
+          }
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e >= p.N) continue;
+            float t = act_apply(v[e] + (p.bias ? p.bias[n + e] : 0.f), p.act);
+            if (!keep) t = 0.f;
+            if (rv) t += rv[n + e];
+            if (p.res1) t += p.res1[(long)m * p.ldr1 + n + e];
+            if (p.res2) t += p.res2[(long)m * p.ldr2 + n + e];
+            t *= p.out_scale;
+            if (p.accumulate) t += o[e];
+            o[e] = t;
+          }
+        }
+      }
+    };
+    pass(std::integral_constant<int, 0>{});
+    if constexpr (MT > 1) pass(std::integral_constant<int, 1>{});
+  } else {
+    // LayerNorm over the 256 output columns: 32 rows at a time through LDS, 8 threads per row.
+    static_assert(!LN || (BN == 256 && BM == WM), "LN variant: one workgroup owns whole 256-wide rows");
+    const int row = tid >> 3, sub = tid & 7;
+    auto pass = [&](auto mt_tag) {
+      constexpr int mt = decltype(mt_tag)::value;
+      __syncthreads();
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int nl = wn * WN + nt * 32 + r32;
+        const float bn = p.bias ? p.bias[nl] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) smem[((e & 3) + 8 * (e >> 2) + 4 * half) * LN_STRIDE + nl] = acc[mt][nt][e] + bn;
+      }
+      __syncthreads();
+      float4 x[8];
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        x[i] = *reinterpret_cast<const float4*>(smem + row * LN_STRIDE + 32 * i + 4 * sub);
+        sum += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+      }
+      sum += __shfl_xor(sum, 1);
+      sum += __shfl_xor(sum, 2);
+      sum += __shfl_xor(sum, 4);
+      const float mean = sum * (1.f / 256.f);
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float a = x[i].x - mean, b = x[i].y - mean, cc = x[i].z - mean, d = x[i].w - mean;
+        sq += (a * a + b * b) + (cc * cc + d * d);
+      }
+      sq += __shfl_xor(sq, 1);
+      sq += __shfl_xor(sq, 2);
+      sq += __shfl_xor(sq, 4);
+      const float rstd = 1.0f / sqrtf(sq * (1.f / 256.f) + p.ln_eps);
+      const int m = m0 + mt * 32 + row;
+      if (m < p.M) {
+        const bool keep = !p.rowmask_out || p.rowmask_out[m];
+        const float* rv = p.rowvec ? p.rowvec + (long)p.row_sample[m] * p.rowvec_ld : nullptr;
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {
+          const int n = 32 * i + 4 * sub;
+          const float4 xi = *reinterpret_cast<const float4*>(smem + row * LN_STRIDE + n);
+          const float4 g = *reinterpret_cast<const float4*>(p.ln_g + n);
+          const float4 be = *reinterpret_cast<const float4*>(p.ln_b + n);
+          float v[4] = {(xi.x - mean) * rstd * g.x + be.x, (xi.y - mean) * rstd * g.y + be.y,
+                        (xi.z - mean) * rstd * g.z + be.z, (xi.w - mean) * rstd * g.w + be.w};
+          float r1[4] = {0, 0, 0, 0};
+          if (p.res1) { const float4 t = *reinterpret_cast<const float4*>(p.res1 + (long)m * p.ldr1 + n); r1[0] = t.x; r1[1] = t.y; r1[2] = t.z; r1[3] = t.w; }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = act_apply(v[e], p.act);
+            if (!keep) t = 0.f;
+            if (rv) t += rv[n + e];
+            if (p.res1) t += r1[e];
+            v[e] = t * p.out_scale;
+          }
+          *reinterpret_cast<float4*>(out + (long)m * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    };
+    pass(std::integral_constant<int, 0>{});
+    if constexpr (MT > 1) pass(std::integral_constant<int, 1>{});
+  }
+}
+
+void conv_gemm_defaults(ConvGemmArgs& a) {
+  a = ConvGemmArgs{};
+  a.ntaps = 1;
+  a.tap_dil = 1;
+  a.out_scale = 1.f;
+  a.nb2 = 1;
+  a.ln_eps = 1e-5f;
+}
+
+namespace {
+
+template <int BM, int BN, int WM, int WN, int NAMAX, bool LN, int PRO>
+int launch1(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
+  const int win = BM + (a.ntaps - 1) * a.tap_dil;
+  if (win > 32 * NAMAX) return fail(JV_ERR_ARG, "conv_gemm: window too tall for this tile variant");
+  size_t lds = (size_t)(win + BN) * LDS_STRIDE * sizeof(float);
+  const size_t need = LN ? (size_t)32 * LN_STRIDE * sizeof(float) : (size_t)4 * 32 * (WN + 4) * sizeof(float);
+  if (lds < need) lds = need;
+  dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), nbatch);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, NAMAX, LN, PRO>), grid, dim3(256), lds, st, a);
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int NAMAX>
+int launch(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
+  switch (a.pro) {
+    case PRO_NONE: return launch1<BM, BN, WM, WN, NAMAX, false, PRO_NONE>(a, nbatch, st);
+    case PRO_SNAKE: return launch1<BM, BN, WM, WN, NAMAX, false, PRO_SNAKE>(a, nbatch, st);
+    case PRO_LRELU: return launch1<BM, BN, WM, WN, NAMAX, false, PRO_LRELU>(a, nbatch, st);
+    default: return fail(JV_ERR_ARG, "conv_gemm: unknown prologue");
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int NAMAX, bool LN, int PRO>
+int raise_lds() {
+  JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, NAMAX, LN, PRO>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  return JV_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int NAMAX>
+int raise_lds3() {
+  JV_TRY((raise_lds<BM, BN, WM, WN, NAMAX, false, PRO_NONE>()));
+  JV_TRY((raise_lds<BM, BN, WM, WN, NAMAX, false, PRO_SNAKE>()));
+  JV_TRY((raise_lds<BM, BN, WM, WN, NAMAX, false, PRO_LRELU>()));
+  return JV_OK;
+}
+
+}  // namespace
+
+int conv_gemm_init() {
+  JV_TRY((raise_lds3<128, 128, 64, 64, 6>()));
+  JV_TRY((raise_lds3<64, 128, 32, 64, 4>()));
+  JV_TRY((raise_lds3<64, 64, 32, 32, 4>()));
+  JV_TRY((raise_lds<64, 256, 64, 64, 3, true, PRO_NONE>()));
+  return JV_OK;
+}
+
+int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
+  if (a.M <= 0 || a.N <= 0) return JV_OK;
+  if (a.Cin <= 0 || (a.Cin & 31)) return fail(JV_ERR_ARG, "conv_gemm: Cin must be a positive multiple of 32");
+  if ((a.lda & 3) || (a.ldw & 3)) return fail(JV_ERR_ARG, "conv_gemm: lda/ldw must be multiples of 4 floats");
+  if (a.ntaps < 1 || a.tap_dil < 1) return fail(JV_ERR_ARG, "conv_gemm: bad taps");
+  if (a.n_rows_w < a.N) return fail(JV_ERR_ARG, "conv_gemm: weight has fewer rows than N");
+  if (a.rowvec && !a.row_sample) return fail(JV_ERR_ARG, "conv_gemm: rowvec needs row_sample");
+  if (a.ln) {
+    if (a.N != 256 || nbatch != 1 || a.res2 || a.accumulate || (a.ldo & 3) || (a.res1 && (a.ldr1 & 3)))
+      return fail(JV_ERR_ARG, "conv_gemm: LayerNorm epilogue supports N == 256 only");
+    if (a.pro != PRO_NONE) return fail(JV_ERR_ARG, "conv_gemm: LayerNorm variant has no prologue");
+    return launch1<64, 256, 64, 64, 3, true, PRO_NONE>(a, 1, st);
+  }
+  // Tile choice: the kernel is MFMA-bound, so cost ~ (#workgroup waves over 256 CUs) x tile area,
+  // with a mild penalty for the smaller tiles' lower operand reuse.
+  const int span = (a.ntaps - 1) * a.tap_dil;
+  struct Cand { int bm, bn; double eff; };
+  const Cand cands[3] = {{128, 128, 1.0}, {64, 128, 0.93}, {64, 64, 0.85}};
+  int best = -1;
+  double best_cost = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (i == 0 && 128 + span > 192) continue;
+    if (i > 0 && 64 + span > 128) continue;
+    const long tiles = (long)cdiv(a.M, cands[i].bm) * cdiv(a.N, cands[i].bn) * nbatch;
+    const double cost = (double)cdivl(tiles, 256) * cands[i].bm * cands[i].bn / cands[i].eff;
+    if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+  }
+  switch (best) {
+    case 0: return launch<128, 128, 64, 64, 6>(a, nbatch, st);
+    case 1: return launch<64, 128, 32, 64, 4>(a, nbatch, st);
+    case 2: return launch<64, 64, 32, 32, 4>(a, nbatch, st);
+    default: return fail(JV_ERR_ARG, "conv_gemm: no tile variant fits this tap span");
+  }
+}
+
+}  // namespace jv

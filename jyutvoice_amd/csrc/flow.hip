@@ -1,0 +1,289 @@
+// Flow-matching decoder: one estimator evaluation (jyutvoice/flow/decoder.py:917-1018) and the
+// Euler / classifier-free-guidance solver around it (jyutvoice/flow/flow_matching.py:215-265, 356-401).
+//
+// Everything runs on row buffers [G + b*S + t][C] (jv_common.h): the estimator's `b c t <-> b t c`
+// transposes (decoder.py:950,966) disappear, causal convolutions are 3-tap row-offset GEMMs, and the
+// 2B CFG rows are just more rows.  Per estimator call: 1 input assembly, 3 tiny time-MLP GEMMs,
+// 14 x (3 conv GEMMs) + 56 x (2 LayerNorm + 4 GEMM + 1 attention) + 4 tail launches, all enqueued on the
+// caller's stream with no host synchronisation (graph-capturable).
+#include <math.h>
+
+#include <vector>
+
+#include "jv_model.h"
+#include "jv_ops.h"
+
+namespace jv {
+
+constexpr int FLOW_G = 4;      // leading guard rows (>= causal left context 2)
+constexpr int FLOW_GAP = 4;    // rows between utterances
+
+struct FlowWs {
+  long rows_alloc = 0;      // rows every [*,C] buffer below can hold
+  float *x = nullptr, *mu = nullptr, *cond = nullptr, *spks = nullptr;   // [rows,80] x3, [maxB,80]
+  float *xin = nullptr;                                               // [rows,320]
+  float *h = nullptr, *h2 = nullptr, *res = nullptr, *cat = nullptr;  // [rows,256] x3, [rows,512]
+  float *ln = nullptr, *qkv = nullptr, *att = nullptr, *ff = nullptr; // 256, 1536, 512, 1024
+  float *d = nullptr;                                                 // [rows,80]
+  float *tsin = nullptr, *t1 = nullptr, *tmish = nullptr, *temb = nullptr;
+  float *t_dev = nullptr, *t_table = nullptr, *dt_table = nullptr;
+  unsigned char* rowmask = nullptr;
+  int* row_sample = nullptr;
+  int* lens2 = nullptr;     // [2*maxB]
+  int max_steps = 1024;
+};
+
+static long flow_rows(int B2, int T) { return (long)FLOW_G + (long)B2 * (T + FLOW_GAP); }
+
+int flow_ws_create(Context& c) {
+  FlowWs* w = new FlowWs();
+  c.flow = w;
+  const int B2 = 2 * c.max_batch;
+  w->rows_alloc = round_up((int)flow_rows(B2, c.max_frames), 128) + 256;
+  const size_t R = (size_t)w->rows_alloc;
+  auto F = [&](float** p, size_t floats) { return ws_alloc(c, floats * sizeof(float), reinterpret_cast<void**>(p)); };
+  JV_TRY(F(&w->x, R * 80));
+  JV_TRY(F(&w->mu, R * 80));
+  JV_TRY(F(&w->cond, R * 80));
+  JV_TRY(F(&w->spks, (size_t)B2 * 80));
+  JV_TRY(F(&w->xin, R * 320));
+  JV_TRY(F(&w->h, R * 256));
+  JV_TRY(F(&w->h2, R * 256));
+  JV_TRY(F(&w->res, R * 256));
+  JV_TRY(F(&w->cat, R * 512));
+  JV_TRY(F(&w->ln, R * 256));
+  JV_TRY(F(&w->qkv, R * 1536));
+  JV_TRY(F(&w->att, R * 512));
+  JV_TRY(F(&w->ff, R * 1024));
+  JV_TRY(F(&w->d, R * 80));
+  JV_TRY(F(&w->tsin, (size_t)B2 * 320));
+  JV_TRY(F(&w->t1, (size_t)B2 * 1024));
+  JV_TRY(F(&w->tmish, (size_t)B2 * 1024));
+  JV_TRY(F(&w->temb, (size_t)B2 * EST_NRES * 256));
+  JV_TRY(F(&w->t_dev, (size_t)B2));
+  JV_TRY(F(&w->t_table, (size_t)w->max_steps));
+  JV_TRY(F(&w->dt_table, (size_t)w->max_steps));
+  JV_TRY(ws_alloc(c, R, reinterpret_cast<void**>(&w->rowmask)));
+  JV_TRY(ws_alloc(c, R * sizeof(int), reinterpret_cast<void**>(&w->row_sample)));
+  JV_TRY(ws_alloc(c, (size_t)B2 * sizeof(int), reinterpret_cast<void**>(&w->lens2)));
+  return JV_OK;
+}
+
+namespace {
+
+struct Geo {
+  int B2, T, S;
+  long M;        // rows computed by every GEMM: [0, M)
+  long a_rows;   // rows that may be read
+  const float* t_ptr = nullptr;   // timestep per utterance: t_ptr[b * t_stride]
+  int t_stride = 1;
+};
+
+ConvGemmArgs base_args(const Geo& g, const float* A, int lda, const GemmW& w, float* out, int ldo) {
+  ConvGemmArgs a;
+  conv_gemm_defaults(a);
+  a.A = A; a.lda = lda; a.a_rows = g.a_rows; a.M = (int)g.M;
+  a.Cin = w.Cin; a.ntaps = w.ntaps; a.tap_row0 = 0; a.tap_dil = 1;
+  a.W = w.w; a.ldw = w.ldw; a.n_rows_w = w.n_rows; a.N = w.N; a.bias = w.bias;
+  a.out = out; a.ldo = ldo;
+  return a;
+}
+
+// the estimator body on prepared inputs: ws.xin [rows,320], ws.rowmask/row_sample/lens2, ws.t_dev [B2] -> ws.d [rows,80]
+int estimator_body(Context& c, const Geo& g, hipStream_t st) {
+  FlowWs& w = *c.flow;
+  const EstimatorW& e = c.est;
+  const int B2 = g.B2;
+
+  // ---- timestep embedding: sinusoid -> Linear+SiLU -> Linear (+Mish, the only consumer) -> 14 projections
+  JV_TRY(time_sinusoid(g.t_ptr, g.t_stride, w.tsin, B2, st));
+  {
+    Geo tg{B2, 1, 1, B2, B2, nullptr, 1};
+    ConvGemmArgs a = base_args(tg, w.tsin, 320, e.time1, w.t1, 1024);
+    a.act = ACT_SILU;
+    JV_TRY(conv_gemm(a, 1, st));
+    a = base_args(tg, w.t1, 1024, e.time2, w.tmish, 1024);
+    a.act = ACT_MISH;
+    JV_TRY(conv_gemm(a, 1, st));
+    a = base_args(tg, w.tmish, 1024, e.temb_all, w.temb, EST_NRES * 256);
+    JV_TRY(conv_gemm(a, 1, st));
+  }
+
+  auto causal3 = [&](ConvGemmArgs& a) {   // CausalConv1d k=3: rows t-2, t-1, t of the masked input
+    a.tap_row0 = -2;
+    a.rowmask_in = w.rowmask;
+  };
+  // CausalResnetBlock1D (decoder.py:110-115, 784-795)
+  auto resnet = [&](int i, const float* in, int ldin, float* out, int ldo) -> int {
+    const ResnetW& r = e.res[i];
+    ConvGemmArgs a = base_args(g, in, ldin, r.block1, w.h2, 256);
+    causal3(a);
+    a.ln = 1; a.ln_g = r.ln1.g; a.ln_b = r.ln1.b; a.ln_eps = 1e-5f; a.act = ACT_MISH;
+    a.rowmask_out = w.rowmask;
+    a.rowvec = w.temb + i * 256; a.row_sample = w.row_sample; a.rowvec_ld = EST_NRES * 256;
+    JV_TRY(conv_gemm(a, 1, st));
+    a = base_args(g, in, ldin, r.res, w.res, 256);
+    a.rowmask_in = w.rowmask;
+    JV_TRY(conv_gemm(a, 1, st));
+    a = base_args(g, w.h2, 256, r.block2, out, ldo);
+    causal3(a);
+    a.ln = 1; a.ln_g = r.ln2.g; a.ln_b = r.ln2.b; a.ln_eps = 1e-5f; a.act = ACT_MISH;
+    a.rowmask_out = w.rowmask;
+    a.res1 = w.res; a.ldr1 = 256;
+    return conv_gemm(a, 1, st);
+  };
+  // BasicTransformerBlock (transformer.py:355-443): h -> h, last GEMM may retarget its output
+  auto btb = [&](const BtbW& b, float* h, float* out, int ldo) -> int {
+    JV_TRY(layernorm_rows(h, nullptr, w.ln, b.n1.g, b.n1.b, 1e-5f, g.M, 256, nullptr, st));
+    ConvGemmArgs a = base_args(g, w.ln, 256, b.qkv, w.qkv, 1536);
+    JV_TRY(conv_gemm(a, 1, st));
+    AttnArgs at;
+    at.qkv = w.qkv; at.ld = 1536; at.k_off = 512; at.v_off = 1024; at.out = w.att; at.ldo = 512;
+    at.B = B2; at.H = EST_HEADS; at.G = FLOW_G; at.S = g.S; at.L = g.T; at.lens = w.lens2;
+    JV_TRY(attention64(at, st));
+    a = base_args(g, w.att, 512, b.out, h, 256);
+    a.res1 = h; a.ldr1 = 256;
+    JV_TRY(conv_gemm(a, 1, st));
+    JV_TRY(layernorm_rows(h, nullptr, w.ln, b.n3.g, b.n3.b, 1e-5f, g.M, 256, nullptr, st));
+    a = base_args(g, w.ln, 256, b.ff1, w.ff, 1024);
+    a.act = ACT_GELU;
+    JV_TRY(conv_gemm(a, 1, st));
+    a = base_args(g, w.ff, 1024, b.ff2, out, ldo);
+    a.res1 = h; a.ldr1 = 256;
+    return conv_gemm(a, 1, st);
+  };
+
+  float* skip = w.cat + 256;   // columns [256,512) of the concat buffer
+  // down: resnet -> 4 blocks (result doubles as the skip) -> causal conv
+  JV_TRY(resnet(0, w.xin, 320, w.h, 256));
+  for (int j = 0; j < EST_NBLK; ++j) JV_TRY(btb(e.blk[0][j], w.h, j == EST_NBLK - 1 ? skip : w.h, j == EST_NBLK - 1 ? 512 : 256));
+  {
+    ConvGemmArgs a = base_args(g, skip, 512, e.down_conv, w.h, 256);
+    causal3(a);
+    JV_TRY(conv_gemm(a, 1, st));
+  }
+  // mid x12; the last block writes straight into columns [0,256) of the concat buffer
+  for (int i = 1; i <= EST_NMID; ++i) {
+    JV_TRY(resnet(i, w.h, 256, w.h, 256));
+    for (int j = 0; j < EST_NBLK; ++j) {
+      const bool last = (i == EST_NMID) && (j == EST_NBLK - 1);
+      JV_TRY(btb(e.blk[i][j], w.h, last ? w.cat : w.h, last ? 512 : 256));
+    }
+  }
+  // up: resnet(cat[x, skip]) -> 4 blocks -> causal conv -> final block -> 1x1 projection
+  JV_TRY(resnet(EST_NRES - 1, w.cat, 512, w.h, 256));
+  for (int j = 0; j < EST_NBLK; ++j) JV_TRY(btb(e.blk[EST_NRES - 1][j], w.h, w.h, 256));
+  {
+    ConvGemmArgs a = base_args(g, w.h, 256, e.up_conv, w.h2, 256);
+    causal3(a);
+    JV_TRY(conv_gemm(a, 1, st));
+    a = base_args(g, w.h2, 256, e.final_conv, w.h, 256);
+    causal3(a);
+    a.ln = 1; a.ln_g = e.final_ln.g; a.ln_b = e.final_ln.b; a.ln_eps = 1e-5f; a.act = ACT_MISH;
+    a.rowmask_out = w.rowmask;
+    JV_TRY(conv_gemm(a, 1, st));
+    a = base_args(g, w.h, 256, e.final_proj, w.d, 80);
+    a.rowmask_in = w.rowmask;
+    a.rowmask_out = w.rowmask;
+    JV_TRY(conv_gemm(a, 1, st));
+  }
+  return JV_OK;
+}
+
+int check_shape(Context& c, int B2, int T) {
+  if (!c.ready[MODEL_TTS]) return fail(JV_ERR_STATE, "tts weights not finalized");
+  if (B2 < 1 || T < 1) return fail(JV_ERR_ARG, "batch and frame count must be positive");
+  if (B2 > 2 * c.max_batch || T > c.max_frames || flow_rows(B2, T) + 128 > c.flow->rows_alloc)
+    return fail(JV_ERR_SHAPE, "batch/frames exceed the capacity given to jv_create");
+  return JV_OK;
+}
+
+}  // namespace
+
+// In a resnet whose input and output are the same buffer (mid blocks), block2 writes `out` only after
+// block1 and res_conv have consumed `in`; stream order makes that safe.
+
+int flow_estimator(Context& c, const float* x, const int* lens_dev, const float* mu, const float* t_dev, const float* spks,
+                   const float* cond, int B2, int T, float* out, hipStream_t st) {
+  JV_TRY(check_shape(c, B2, T));
+  FlowWs& w = *c.flow;
+  Geo g{B2, T, T + FLOW_GAP, flow_rows(B2, T), w.rows_alloc, w.t_dev, 1};
+  // channels-first [B2,80,T] inputs -> row buffers (reusing x/mu/cond, which hold 2B utterances here)
+  JV_TRY(cf_to_rows(x, 80L * T, T, B2, 80, T, w.x, 80, 0, FLOW_G, g.S, 1.f, nullptr, st));
+  JV_TRY(cf_to_rows(mu, 80L * T, T, B2, 80, T, w.mu, 80, 0, FLOW_G, g.S, 1.f, nullptr, st));
+  JV_TRY(cf_to_rows(cond, 80L * T, T, B2, 80, T, w.cond, 80, 0, FLOW_G, g.S, 1.f, nullptr, st));
+  if (lens_dev) JV_HIP(hipMemcpyAsync(w.lens2, lens_dev, sizeof(int) * B2, hipMemcpyDeviceToDevice, st));
+  else JV_TRY(fill_int(w.lens2, T, B2, st));
+  JV_TRY(row_meta(w.rowmask, w.row_sample, w.lens2, B2, 1, FLOW_G, g.S, T, w.rows_alloc, 1, 0, st));
+  JV_HIP(hipMemcpyAsync(w.t_dev, t_dev, sizeof(float) * B2, hipMemcpyDeviceToDevice, st));
+  JV_TRY(assemble_xin_plain(w.x, w.mu, spks, w.cond, w.xin, B2, FLOW_G, g.S, T, g.M, st));
+  JV_TRY(estimator_body(c, g, st));
+  return rows_to_cf(w.d, 80, 0, FLOW_G, g.S, out, 80L * T, B2, 80, T, nullptr, st);
+}
+
+int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spks, const float* cond, int B, int T,
+              int n_timesteps, float temperature, const float* t_span_host, float* mel, hipStream_t st) {
+  JV_TRY(check_shape(c, 2 * B, T));
+  if (!c.noise_loaded) return fail(JV_ERR_STATE, "CFM noise tensor not loaded (jv_load_noise)");
+  if (T > NOISE_FRAMES) return fail(JV_ERR_SHAPE, "more frames than the fixed noise tensor holds (15000)");
+  FlowWs& w = *c.flow;
+  if (n_timesteps < 1 || n_timesteps > w.max_steps) return fail(JV_ERR_ARG, "n_timesteps out of range");
+  const int B2 = 2 * B;
+  Geo g{B2, T, T + FLOW_GAP, flow_rows(B2, T), w.rows_alloc, nullptr, 0};
+
+  // cosine schedule and the reference's running (t, dt) recurrence, in fp32 (flow_matching.py:230,260-263,387-389)
+  std::vector<float> ts(n_timesteps + 1), tt(n_timesteps), dts(n_timesteps);
+  if (t_span_host) {
+    for (int i = 0; i <= n_timesteps; ++i) ts[i] = t_span_host[i];
+  } else {
+    const int steps = n_timesteps + 1;
+    const float step = 1.0f / (float)(steps - 1);
+    for (int i = 0; i < steps; ++i) {
+      const float lin = i < steps / 2 ? step * (float)i : 1.0f - step * (float)(steps - 1 - i);
+      ts[i] = 1.0f - cosf(lin * 0.5f * 3.14159265358979323846f);
+    }
+  }
+  {
+    float t = ts[0], dt = ts[1] - ts[0];
+    for (int s = 1; s <= n_timesteps; ++s) {
+      tt[s - 1] = t;
+      dts[s - 1] = dt;
+      t = t + dt;
+      if (s < n_timesteps) dt = ts[s + 1] - t;
+    }
+  }
+  JV_HIP(hipMemcpyAsync(w.t_table, tt.data(), sizeof(float) * n_timesteps, hipMemcpyHostToDevice, st));
+  JV_HIP(hipMemcpyAsync(w.dt_table, dts.data(), sizeof(float) * n_timesteps, hipMemcpyHostToDevice, st));
+  // pageable-host staging vectors die at scope exit: make sure the copies have been consumed
+  JV_HIP(hipStreamSynchronize(st));
+
+  // per-solve preparation: lengths (duplicated for the CFG twin rows), masks, row-layout mu / cond / z
+  if (lens_dev) {
+    JV_HIP(hipMemcpyAsync(w.lens2, lens_dev, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+    JV_HIP(hipMemcpyAsync(w.lens2 + B, lens_dev, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+  } else {
+    JV_TRY(fill_int(w.lens2, T, B2, st));
+  }
+  JV_TRY(row_meta(w.rowmask, w.row_sample, w.lens2, B2, 1, FLOW_G, g.S, T, w.rows_alloc, 1, 0, st));
+  JV_TRY(cf_to_rows(mu, 80L * T, T, B, 80, T, w.mu, 80, 0, FLOW_G, g.S, 1.f, nullptr, st));
+  JV_TRY(cf_to_rows(cond, 80L * T, T, B, 80, T, w.cond, 80, 0, FLOW_G, g.S, 1.f, nullptr, st));
+  // z = rand_noise[:, :, :T] * temperature, the same prefix for every utterance (flow_matching.py:385)
+  JV_TRY(cf_to_rows(c.noise, 0, NOISE_FRAMES, B, 80, T, w.x, 80, 0, FLOW_G, g.S, temperature, nullptr, st));
+
+  for (int s = 0; s < n_timesteps; ++s) {
+    JV_TRY(assemble_xin(w.x, w.mu, spks, w.cond, w.xin, B, FLOW_G, g.S, T, g.M, st));
+    g.t_ptr = w.t_table + s;   // the same t for all 2B rows (stride 0)
+    JV_TRY(estimator_body(c, g, st));
+    JV_TRY(euler_cfg(w.x, w.d, B, FLOW_G, g.S, T, w.dt_table, s, 0.7f, st));
+  }
+  return rows_to_cf(w.x, 80, 0, FLOW_G, g.S, mel, 80L * T, B, 80, T, lens_dev ? w.lens2 : nullptr, st);
+}
+
+}  // namespace jv
+
+namespace jv {
+void flow_ws_destroy(Context& c) {
+  delete c.flow;
+  c.flow = nullptr;
+}
+}  // namespace jv

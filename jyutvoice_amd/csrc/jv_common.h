@@ -1,0 +1,112 @@
+// Shared declarations for libjyutvoice_hip.so (gfx950 / CDNA4 only).
+//
+// Data layout used by every kernel in this library ("row buffers"):
+//   an activation is a row-major [rows, C] fp32 matrix, one row per time step (mel frame, token or
+//   audio-rate sample), channels contiguous.  Utterance b's step t lives at row G + b*S + t, where
+//   G is a leading guard band and S = L + gap the per-utterance stride; the gap rows between
+//   utterances double as the zero padding every convolution of the path needs, so a conv tap is just
+//   a row offset and an utterance batch is one flat GEMM M dimension.  A byte-per-row `rowmask` says
+//   which rows are real frames; kernels *select* zero for masked rows (never multiply), so guard
+//   rows may hold garbage.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#define JV_OK 0
+#define JV_ERR_ARG 1
+#define JV_ERR_STATE 2
+#define JV_ERR_HIP 3
+#define JV_ERR_SHAPE 4
+#define JV_ERR_NAME 5
+
+namespace jv {
+
+void set_error(const std::string& msg);          // thread-local last error (api.hip)
+int fail(int code, const std::string& msg);      // set_error + return code
+
+#define JV_HIP(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return ::jv::fail(JV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+  } while (0)
+
+#define JV_TRY(expr)              \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc != JV_OK) return _rc; \
+  } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline long cdivl(long a, long b) { return (a + b - 1) / b; }
+inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// ---- implicit-GEMM convolution (conv_gemm.hip) -------------------------------------------------
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_MISH = 3, ACT_ELU = 4, ACT_SILU = 5 };
+enum Pro : int { PRO_NONE = 0, PRO_SNAKE = 1, PRO_LRELU = 2 };
+
+struct ConvGemmArgs {
+  // A: row buffer.  Output row m, tap j reads A row (m + tap_row0 + j*tap_dil), channels [0,Cin).
+  const float* A;
+  long lda;        // floats between consecutive A rows
+  long a_rows;     // rows of A that may be read; rows outside [0,a_rows) read as zero
+  int M;           // output rows
+  int Cin;         // channels per tap, multiple of 32
+  int ntaps, tap_row0, tap_dil;
+  // W: packed [n_rows_w][ldw], K-contiguous: column j*Cin + ci multiplies tap j, channel ci
+  const float* W;
+  int ldw;
+  int n_rows_w;    // rows of W that may be read (>= N, zero padded)
+  int N;           // valid output columns
+  const float* bias;               // [N] or null
+  float* out;
+  long ldo;
+  // prologue (applied to A while staging it into LDS)
+  int pro;
+  const float* pro_alpha;          // PRO_SNAKE: per input channel
+  float pro_slope;                 // PRO_LRELU
+  const unsigned char* rowmask_in; // per A row, or null: 0 -> row reads as zero
+  // epilogue, in this order
+  int ln;                          // LayerNorm over the N columns (LN tile variant only)
+  const float* ln_g;
+  const float* ln_b;
+  float ln_eps;
+  int act;
+  const unsigned char* rowmask_out;  // per output row, or null: 0 -> value := 0
+  const float* rowvec;             // + rowvec[row_sample[m]*rowvec_ld + n]
+  const int* row_sample;
+  int rowvec_ld;
+  const float* res1;               // + res1[m*ldr1 + n]
+  long ldr1;
+  const float* res2;
+  long ldr2;
+  float out_scale;                 // * out_scale
+  int accumulate;                  // += previous out value
+  // optional batch (grid.z = nb1*nb2): pointers advance by z1*s?1 + z2*s?2 floats
+  int nb2;
+  long sA1, sA2, sW1, sW2, sO1, sO2;
+};
+
+void conv_gemm_defaults(ConvGemmArgs& a);
+int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st);
+int conv_gemm_init();   // raises the dynamic-LDS limit of every instantiation
+
+// ---- attention (attention.hip) -----------------------------------------------------------------
+struct AttnArgs {
+  const float* qkv;   // [rows, ld] with q at col 0, k at col k_off, v at col v_off (+ head*64)
+  long ld;
+  int k_off, v_off;
+  float* out;         // [rows, ldo], head h writes cols [h*64, h*64+64)
+  long ldo;
+  int B, H;
+  int G, S, L;        // row geometry: utterance b, frame t at row G + b*S + t, t < L
+  const int* lens;    // [B] valid keys per utterance (device), or null = L
+};
+int attention64(const AttnArgs& a, hipStream_t st);
+
+// ---- row-wise / elementwise kernels (rowops.hip) -------------------------------------------------
+int layernorm_rows(const float* x, const float* add, float* out, const float* g, const float* b, float eps, long rows,
+                   int C, const unsigned char* rowmask_out, hipStream_t st);
+
+}  // namespace jv

@@ -1,0 +1,122 @@
+// Context, weight registry and per-stage weight views of libjyutvoice_hip.so.
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "jv_common.h"
+
+namespace jv {
+
+// ---- architecture constants (configs/base.yaml:1-110 of the reference; mirrored by spec.py) ------
+constexpr int N_FEATS = 80;
+constexpr int SPK_DIM = 192;
+constexpr int ENC_CH = 192, ENC_HID = 576, ENC_FILTER = 768, ENC_HEADS = 2, ENC_HEAD_DIM = 288, ENC_ROPE = 144,
+              ENC_LAYERS = 6;
+constexpr int DP_FILTER = 256;
+constexpr int EST_IN = 320, EST_CH = 256, EST_TIME = 1024, EST_HEADS = 8, EST_INNER = 512, EST_FF = 1024, EST_NBLK = 4,
+              EST_NMID = 12, EST_NRES = 14;
+constexpr int NOISE_FRAMES = 15000;
+constexpr int HIFT_CH = 512, HIFT_F0_CH = 512, HIFT_NFFT = 16, HIFT_HOP = 4, HIFT_HARM = 9;
+
+enum Model : int { MODEL_TTS = 0, MODEL_HIFT = 1 };
+
+struct RawTensor {
+  std::string name;
+  std::vector<int64_t> shape;
+  long numel = 0;
+  float* dev = nullptr;
+  bool loaded = false;
+  int model = 0;
+};
+
+// simple bump allocator over hipMalloc'd chunks (device memory only; never freed before destroy)
+struct Arena {
+  std::vector<void*> chunks;
+  size_t chunk_floats = (size_t)64 << 20;   // 256 MiB
+  size_t used = 0, cap = 0;
+  float* cur = nullptr;
+  int alloc(size_t floats, float** out);     // 256-byte aligned
+  void release();
+};
+
+// a packed weight matrix for conv_gemm: rows = output channels, K-contiguous, column j*Cin + ci
+struct GemmW {
+  const float* w = nullptr;
+  int ldw = 0, n_rows = 0, N = 0, Cin = 0, ntaps = 1;
+  const float* bias = nullptr;
+};
+
+struct LnW { const float* g = nullptr; const float* b = nullptr; };
+
+struct ResnetW { GemmW block1, block2, res; LnW ln1, ln2; };
+struct BtbW { LnW n1, n3; GemmW qkv, out, ff1, ff2; };
+struct EstimatorW {
+  GemmW time1, time2, temb_all;
+  ResnetW res[EST_NRES];                 // 0 = down, 1..12 = mid, 13 = up
+  BtbW blk[EST_NRES][EST_NBLK];
+  GemmW down_conv, up_conv, final_conv, final_proj;
+  LnW final_ln;
+};
+
+struct EncLayerW { GemmW qkv, o, ffn1, ffn2; LnW n1, n2; };
+struct EncoderW {
+  const float *emb = nullptr, *lang_emb = nullptr, *tone_emb = nullptr, *wpos_emb = nullptr, *spos_emb = nullptr;
+  GemmW pre_conv[3], pre_proj;
+  LnW pre_ln[3];
+  EncLayerW layer[ENC_LAYERS];
+  GemmW proj;
+  GemmW dp_cond, dp_conv1, dp_conv2, dp_proj;
+  LnW dp_ln1, dp_ln2;
+  GemmW spk_affine;
+};
+
+struct ResBlockW { GemmW c1[3], c2[3]; const float* a1[3]; const float* a2[3]; int k = 0; };
+struct HiftW {
+  GemmW f0_conv[5];
+  const float *f0_cls_w = nullptr, *f0_cls_b = nullptr;
+  const float *src_lin_w = nullptr, *src_lin_b = nullptr;
+  GemmW conv_pre, ups[3], src_down[3], conv_post;
+  ResBlockW src_rb[3], rb[9];
+};
+
+struct Buf {             // a device allocation owned by the context
+  float* p = nullptr;
+  size_t floats = 0;
+};
+
+struct Context {
+  int device = 0;
+  int max_batch = 0, max_frames = 0, max_tokens = 0;
+  std::vector<RawTensor> raw;
+  std::unordered_map<std::string, int> index;
+  Arena raw_arena, packed;
+  bool ready[2] = {false, false};
+  EstimatorW est;
+  EncoderW enc;
+  HiftW hift;
+  float* noise = nullptr;        // [80][15000] fixed CFM noise (device), supplied by the host
+  bool noise_loaded = false;
+  // workspace
+  std::vector<void*> ws_allocs;
+  struct FlowWs* flow = nullptr;
+  struct HiftWs* hws = nullptr;
+  struct EncWs* ews = nullptr;
+  std::string last_error;
+};
+
+// registry.hip
+void build_registry(Context& c);
+int finalize_model(Context& c, int model, hipStream_t st);
+
+// workspace helpers (api.hip)
+int ws_alloc(Context& c, size_t bytes, void** out);
+
+// flow.hip
+int flow_ws_create(Context& c);
+int flow_estimator(Context& c, const float* x, const int* lens_dev, const float* mu, const float* t_dev, const float* spks,
+                   const float* cond, int B2, int T, float* out, hipStream_t st);
+int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spks, const float* cond, int B, int T,
+              int n_timesteps, float temperature, const float* t_span_host, float* mel, hipStream_t st);
+
+}  // namespace jv

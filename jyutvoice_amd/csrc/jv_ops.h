@@ -1,0 +1,24 @@
+// Declarations of the small row-buffer kernels (rowops.hip, hiftops.hip, encops.hip).
+#pragma once
+#include "jv_common.h"
+
+namespace jv {
+
+int row_meta(unsigned char* rowmask, int* row_sample, const int* lens, int nb, int reps, int G, int S, int L, long rows,
+             int mul, int add, hipStream_t st);
+// src[b*src_bstride + c*pitch + t] (channels-first) -> dst[(G + b*S + t)*ld + col0 + c]
+int cf_to_rows(const float* src, long src_bstride, long pitch, int B, int C, int T, float* dst, int ld, int col0, int G,
+               int S, float scale, const int* lens, hipStream_t st);
+int rows_to_cf(const float* src, int ld, int col0, int G, int S, float* dst, long dst_bstride, int B, int C, int T,
+               const int* lens, hipStream_t st);
+int assemble_xin(const float* x, const float* mu, const float* spks, const float* cond, float* xin, int B, int G, int S,
+                 int L, long rows2, hipStream_t st);
+int assemble_xin_plain(const float* x, const float* mu, const float* spks, const float* cond, float* xin, int B, int G,
+                       int S, int L, long rows, hipStream_t st);
+int time_sinusoid(const float* t, int t_stride, float* out, int B, hipStream_t st);
+int euler_cfg(float* x, const float* d, int B, int G, int S, int L, const float* dt_table, int step, float rate,
+              hipStream_t st);
+int fill(float* p, float v, long n, hipStream_t st);
+int fill_int(int* p, int v, long n, hipStream_t st);
+
+}  // namespace jv

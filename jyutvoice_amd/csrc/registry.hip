@@ -1,0 +1,448 @@
+// Weight registry (checkpoint tensor names/shapes the library accepts) and load-time packing.
+//
+// Names and shapes are exactly the reference's state-dict keys:
+//   tts : encoder.* (117), dp.* (12), decoder.estimator.* (910), spk_embed_affine_layer.* (2)
+//         -- jyutvoice/models/jyutvoice_tts.py:42-49, configs/base.yaml:50-110
+//   hift: 328 keys, weight-norm as parametrizations.weight.original0/1 (generator.py:26) and
+//         weight_g/weight_v (f0_predictor.py:16)
+// finalize_model() folds weight-norm (w = v * g/||v||, torch._weight_norm), re-lays convolution
+// kernels [Cout][Cin][k] as K-contiguous GEMM operands [Cout][k*Cin] (tap-major), fuses q/k/v and the
+// 14 per-resnet time projections into single matrices, and rewrites each ConvTranspose1d as a
+// polyphase matrix [stride*Cout][3*Cin].
+#include <math.h>
+
+#include "jv_model.h"
+
+namespace jv {
+
+// ------------------------------------------------------------------------------------------------
+int Arena::alloc(size_t floats, float** out) {
+  floats = (floats + 63) & ~(size_t)63;
+  if (!cur || used + floats > cap) {
+    const size_t n = floats > chunk_floats ? floats : chunk_floats;
+    void* p = nullptr;
+    JV_HIP(hipMalloc(&p, n * sizeof(float)));
+    chunks.push_back(p);
+    cur = static_cast<float*>(p);
+    cap = n;
+    used = 0;
+  }
+  *out = cur + used;
+  used += floats;
+  return JV_OK;
+}
+
+void Arena::release() {
+  for (void* p : chunks) (void)hipFree(p);
+  chunks.clear();
+  cur = nullptr;
+  used = cap = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Reg {
+  Context& c;
+  int model;
+  void add(const std::string& name, std::vector<int64_t> shape) {
+    RawTensor t;
+    t.name = name;
+    t.shape = std::move(shape);
+    t.numel = 1;
+    for (auto s : t.shape) t.numel *= s;
+    t.model = model;
+    c.index[name] = (int)c.raw.size();
+    c.raw.push_back(std::move(t));
+  }
+  void wb(const std::string& p, std::vector<int64_t> wshape) {   // weight + bias
+    const int64_t n = wshape[0];
+    add(p + "weight", std::move(wshape));
+    add(p + "bias", {n});
+  }
+  void gb(const std::string& p, int64_t n, const char* g = "gamma", const char* b = "beta") {
+    add(p + g, {n});
+    add(p + b, {n});
+  }
+};
+
+std::string S(int i) { return std::to_string(i); }
+
+}  // namespace
+
+void build_registry(Context& c) {
+  Reg r{c, MODEL_TTS};
+  // ---- encoder.* (text_encoder.py:340-404) -----------------------------------------------------
+  const std::string e = "encoder.";
+  r.add(e + "emb.weight", {97, ENC_CH});
+  r.add(e + "lang_emb.weight", {4, ENC_CH});
+  r.add(e + "tone_emb.weight", {7, ENC_CH});
+  r.add(e + "word_pos_emb.weight", {4, ENC_CH});
+  r.add(e + "syllable_pos.weight", {4, ENC_CH});
+  for (int i = 0; i < 3; ++i) {
+    r.wb(e + "prenet.conv_layers." + S(i) + ".", {ENC_CH, ENC_CH, 5});
+    r.gb(e + "prenet.norm_layers." + S(i) + ".", ENC_CH);
+  }
+  r.wb(e + "prenet.proj.", {ENC_CH, ENC_CH, 1});
+  for (int i = 0; i < ENC_LAYERS; ++i) {
+    for (const char* n : {"q", "k", "v", "o"})
+      r.wb(e + "encoder.attn_layers." + S(i) + ".conv_" + n + ".", {ENC_HID, ENC_HID, 1});
+    r.gb(e + "encoder.norm_layers_1." + S(i) + ".", ENC_HID);
+    r.wb(e + "encoder.ffn_layers." + S(i) + ".conv_1.", {ENC_FILTER, ENC_HID, 3});
+    r.wb(e + "encoder.ffn_layers." + S(i) + ".conv_2.", {ENC_HID, ENC_FILTER, 3});
+    r.gb(e + "encoder.norm_layers_2." + S(i) + ".", ENC_HID);
+  }
+  r.wb(e + "proj.", {N_FEATS, ENC_HID, 1});
+  // ---- dp.* (duration_predictor.py:26-46) --------------------------------------------------------
+  r.wb("dp.conv_1.", {DP_FILTER, ENC_HID, 3});
+  r.gb("dp.norm_1.", DP_FILTER);
+  r.wb("dp.conv_2.", {DP_FILTER, DP_FILTER, 3});
+  r.gb("dp.norm_2.", DP_FILTER);
+  r.wb("dp.proj.", {1, DP_FILTER, 1});
+  r.wb("dp.cond.", {ENC_HID, SPK_DIM, 1});
+  // ---- decoder.estimator.* (decoder.py:798-915) ----------------------------------------------------
+  const std::string p = "decoder.estimator.";
+  r.wb(p + "time_mlp.linear_1.", {EST_TIME, EST_IN});
+  r.wb(p + "time_mlp.linear_2.", {EST_TIME, EST_TIME});
+  auto resnet = [&](const std::string& q, int cin) {
+    r.wb(q + "mlp.1.", {EST_CH, EST_TIME});
+    r.wb(q + "block1.block.0.", {EST_CH, cin, 3});
+    r.gb(q + "block1.block.2.", EST_CH, "weight", "bias");
+    r.wb(q + "block2.block.0.", {EST_CH, EST_CH, 3});
+    r.gb(q + "block2.block.2.", EST_CH, "weight", "bias");
+    r.wb(q + "res_conv.", {EST_CH, cin, 1});
+  };
+  auto btb = [&](const std::string& q) {
+    r.gb(q + "norm1.", EST_CH, "weight", "bias");
+    r.add(q + "attn1.to_q.weight", {EST_INNER, EST_CH});
+    r.add(q + "attn1.to_k.weight", {EST_INNER, EST_CH});
+    r.add(q + "attn1.to_v.weight", {EST_INNER, EST_CH});
+    r.wb(q + "attn1.to_out.0.", {EST_CH, EST_INNER});
+    r.gb(q + "norm3.", EST_CH, "weight", "bias");
+    r.wb(q + "ff.net.0.proj.", {EST_FF, EST_CH});
+    r.wb(q + "ff.net.2.", {EST_CH, EST_FF});
+  };
+  resnet(p + "down_blocks.0.0.", EST_IN);
+  for (int j = 0; j < EST_NBLK; ++j) btb(p + "down_blocks.0.1." + S(j) + ".");
+  r.wb(p + "down_blocks.0.2.", {EST_CH, EST_CH, 3});
+  for (int i = 0; i < EST_NMID; ++i) {
+    resnet(p + "mid_blocks." + S(i) + ".0.", EST_CH);
+    for (int j = 0; j < EST_NBLK; ++j) btb(p + "mid_blocks." + S(i) + ".1." + S(j) + ".");
+  }
+  resnet(p + "up_blocks.0.0.", 2 * EST_CH);
+  for (int j = 0; j < EST_NBLK; ++j) btb(p + "up_blocks.0.1." + S(j) + ".");
+  r.wb(p + "up_blocks.0.2.", {EST_CH, EST_CH, 3});
+  r.wb(p + "final_block.block.0.", {EST_CH, EST_CH, 3});
+  r.gb(p + "final_block.block.2.", EST_CH, "weight", "bias");
+  r.wb(p + "final_proj.", {N_FEATS, EST_CH, 1});
+  r.wb("spk_embed_affine_layer.", {N_FEATS, SPK_DIM});
+
+  // ---- hift (generator.py:245-355, f0_predictor.py:8-50) ----------------------------------------------
+  Reg h{c, MODEL_HIFT};
+  auto wn = [&](const std::string& q, std::vector<int64_t> shape, int64_t nbias) {
+    h.add(q + "bias", {nbias});
+    h.add(q + "parametrizations.weight.original0", {shape[0], 1, 1});
+    h.add(q + "parametrizations.weight.original1", std::move(shape));
+  };
+  h.wb("m_source.l_linear.", {1, HIFT_HARM});
+  wn("conv_pre.", {HIFT_CH, N_FEATS, 7}, HIFT_CH);
+  const int up_k[3] = {16, 11, 7};
+  for (int i = 0; i < 3; ++i) wn("ups." + S(i) + ".", {HIFT_CH >> i, HIFT_CH >> (i + 1), up_k[i]}, HIFT_CH >> (i + 1));
+  const int sd_k[3] = {30, 6, 1};
+  for (int i = 0; i < 3; ++i) h.wb("source_downs." + S(i) + ".", {HIFT_CH >> (i + 1), HIFT_NFFT + 2, sd_k[i]});
+  auto resblock = [&](const std::string& q, int ch, int k) {
+    for (const char* which : {"convs1.", "convs2."})
+      for (int j = 0; j < 3; ++j) wn(q + which + S(j) + ".", {ch, ch, k}, ch);
+    for (const char* which : {"activations1.", "activations2."})
+      for (int j = 0; j < 3; ++j) h.add(q + which + S(j) + ".alpha", {ch});
+  };
+  const int src_k[3] = {7, 7, 11}, rb_k[3] = {3, 7, 11};
+  for (int i = 0; i < 3; ++i) resblock("source_resblocks." + S(i) + ".", HIFT_CH >> (i + 1), src_k[i]);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) resblock("resblocks." + S(3 * i + j) + ".", HIFT_CH >> (i + 1), rb_k[j]);
+  wn("conv_post.", {HIFT_NFFT + 2, HIFT_CH >> 3, 7}, HIFT_NFFT + 2);
+  for (int n = 0; n < 5; ++n) {
+    const std::string q = "f0_predictor.condnet." + S(2 * n) + ".";
+    h.add(q + "bias", {HIFT_F0_CH});
+    h.add(q + "weight_g", {HIFT_F0_CH, 1, 1});
+    h.add(q + "weight_v", {HIFT_F0_CH, n == 0 ? N_FEATS : HIFT_F0_CH, 3});
+  }
+  h.wb("f0_predictor.classifier.", {1, HIFT_F0_CH});
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// dst[(row0+n)*ldw + j*cinp + ci] = src[n][ci][j]   (zero for ci >= cin)
+__global__ void pack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int k, int cinp,
+                                 int ldw, int row0) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per_n = (long)k * cinp;
+  if (idx >= per_n * cout) return;
+  const int n = (int)(idx / per_n);
+  const int rem = (int)(idx - (long)n * per_n);
+  const int j = rem / cinp, ci = rem - j * cinp;
+  dst[(long)(row0 + n) * ldw + rem] = ci < cin ? src[((long)n * cin + ci) * k + j] : 0.f;
+}
+
+// ConvTranspose1d [cin][cout][k], stride s, padding pad -> polyphase rows n = r*cout + co, 3 taps (rows q-1, q, q+1):
+//   tap jj reads input row q + jj - 1 = q - m with m = 1 - jj and kernel index kk = r + pad + m*s
+__global__ void pack_convT_kernel(const float* __restrict__ src, float* __restrict__ dst, int cin, int cout, int k, int s,
+                                  int pad) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per_n = 3L * cin;
+  const long total = per_n * s * cout;
+  if (idx >= total) return;
+  const int n = (int)(idx / per_n);
+  const int rem = (int)(idx - (long)n * per_n);
+  const int jj = rem / cin, ci = rem - jj * cin;
+  const int r = n / cout, co = n - r * cout;
+  const int kk = r + pad + (1 - jj) * s;
+  dst[idx] = (kk >= 0 && kk < k) ? src[((long)ci * cout + co) * k + kk] : 0.f;
+}
+
+__global__ void tile_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int reps) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n * reps) dst[i] = src[i % n];
+}
+
+// w[r][:] = v[r][:] * (g[r] / ||v[r][:]||)
+__global__ __launch_bounds__(256) void fold_wn_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                      float* __restrict__ w, int cols) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const float* vr = v + (long)r * cols;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < cols; i += 256) s += vr[i] * vr[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+  const float scale = g[r] / sqrtf(tot);
+  for (int i = threadIdx.x; i < cols; i += 256) w[(long)r * cols + i] = vr[i] * scale;
+}
+
+struct Packer {
+  Context& c;
+  hipStream_t st;
+  int rc = JV_OK;
+
+  const RawTensor* get(const std::string& name) {
+    auto it = c.index.find(name);
+    if (it == c.index.end()) { rc = fail(JV_ERR_NAME, "internal: unknown tensor " + name); return nullptr; }
+    const RawTensor& t = c.raw[it->second];
+    if (!t.loaded) { rc = fail(JV_ERR_STATE, "missing tensor: " + name); return nullptr; }
+    return &t;
+  }
+  const float* ptr(const std::string& name) {
+    const RawTensor* t = get(name);
+    return t ? t->dev : nullptr;
+  }
+  float* alloc(size_t n) {
+    float* p = nullptr;
+    if (rc == JV_OK) rc = c.packed.alloc(n, &p);
+    return p;
+  }
+  // plain weight of a weight-normalised layer: fold (g, v) into a scratch matrix of the packed arena
+  const float* folded(const std::string& gname, const std::string& vname) {
+    const RawTensor* g = get(gname);
+    const RawTensor* v = get(vname);
+    if (!g || !v) return nullptr;
+    const int rows = (int)v->shape[0], cols = (int)(v->numel / rows);
+    float* w = alloc(v->numel);
+    if (!w) return nullptr;
+    hipLaunchKernelGGL(fold_wn_kernel, dim3(rows), dim3(256), 0, st, v->dev, g->dev, w, cols);
+    return w;
+  }
+  // conv weight [cout][cin][k] (device, plain) -> GemmW with cin padded to cinp
+  GemmW conv(const float* w, int cout, int cin, int k, int cinp, const float* bias) {
+    GemmW g;
+    if (!w) return g;
+    const int ldw = k * cinp;
+    float* d = alloc((size_t)cout * ldw);
+    if (!d) return g;
+    const long total = (long)cout * ldw;
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, w, d, cout, cin, k, cinp, ldw,
+                       0);
+    g.w = d; g.ldw = ldw; g.n_rows = cout; g.N = cout; g.Cin = cinp; g.ntaps = k; g.bias = bias;
+    return g;
+  }
+  GemmW conv_named(const std::string& p, int cout, int cin, int k, int cinp = 0) {
+    return conv(ptr(p + "weight"), cout, cin, k, cinp ? cinp : cin, ptr(p + "bias"));
+  }
+  GemmW conv_wn(const std::string& p, int cout, int cin, int k, int cinp = 0) {
+    return conv(folded(p + "parametrizations.weight.original0", p + "parametrizations.weight.original1"), cout, cin, k,
+                cinp ? cinp : cin, ptr(p + "bias"));
+  }
+  // [N][K] matrices usable in place (Linear, 1x1 conv)
+  GemmW linear(const std::string& wname, const std::string& bname, int n, int k) {
+    GemmW g;
+    g.w = ptr(wname); g.ldw = k; g.n_rows = n; g.N = n; g.Cin = k; g.ntaps = 1;
+    g.bias = bname.empty() ? nullptr : ptr(bname);
+    return g;
+  }
+  // vertical concatenation of [n_i][k] matrices (+ optional biases)
+  GemmW concat(const std::vector<std::string>& wnames, const std::vector<std::string>& bnames, int n_each, int k) {
+    GemmW g;
+    const int parts = (int)wnames.size();
+    float* d = alloc((size_t)parts * n_each * k);
+    float* b = bnames.empty() ? nullptr : alloc((size_t)parts * n_each);
+    if (!d || (!bnames.empty() && !b)) return g;
+    for (int i = 0; i < parts; ++i) {
+      const float* w = ptr(wnames[i]);
+      if (!w) return g;
+      if (hipMemcpyAsync(d + (size_t)i * n_each * k, w, (size_t)n_each * k * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        rc = fail(JV_ERR_HIP, "concat copy failed");
+      if (b) {
+        const float* bs = ptr(bnames[i]);
+        if (!bs) return g;
+        if (hipMemcpyAsync(b + (size_t)i * n_each, bs, (size_t)n_each * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+          rc = fail(JV_ERR_HIP, "concat copy failed");
+      }
+    }
+    g.w = d; g.ldw = k; g.n_rows = parts * n_each; g.N = parts * n_each; g.Cin = k; g.ntaps = 1; g.bias = b;
+    return g;
+  }
+  GemmW convT_wn(const std::string& p, int cin, int cout, int k, int s) {
+    GemmW g;
+    const float* w = folded(p + "parametrizations.weight.original0", p + "parametrizations.weight.original1");
+    const float* bias = ptr(p + "bias");
+    if (!w || !bias) return g;
+    const long total = 3L * cin * s * cout;
+    float* d = alloc(total);
+    float* b = alloc((size_t)s * cout);
+    if (!d || !b) return g;
+    hipLaunchKernelGGL(pack_convT_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, w, d, cin, cout, k, s,
+                       (k - s) / 2);
+    hipLaunchKernelGGL(tile_bias_kernel, dim3(cdiv(s * cout, 256)), dim3(256), 0, st, bias, b, cout, s);
+    g.w = d; g.ldw = 3 * cin; g.n_rows = s * cout; g.N = s * cout; g.Cin = cin; g.ntaps = 3; g.bias = b;
+    return g;
+  }
+  LnW ln(const std::string& p, const char* gname, const char* bname) { return LnW{ptr(p + gname), ptr(p + bname)}; }
+};
+
+}  // namespace
+
+int finalize_model(Context& c, int model, hipStream_t st) {
+  for (const RawTensor& t : c.raw)
+    if (t.model == model && !t.loaded) return fail(JV_ERR_STATE, "missing tensor: " + t.name);
+  Packer pk{c, st};
+
+  if (model == MODEL_TTS) {
+    // ---------------- estimator ----------------
+    const std::string p = "decoder.estimator.";
+    EstimatorW& e = c.est;
+    e.time1 = pk.linear(p + "time_mlp.linear_1.weight", p + "time_mlp.linear_1.bias", EST_TIME, EST_IN);
+    e.time2 = pk.linear(p + "time_mlp.linear_2.weight", p + "time_mlp.linear_2.bias", EST_TIME, EST_TIME);
+    std::vector<std::string> stage(EST_NRES);
+    stage[0] = p + "down_blocks.0.";
+    for (int i = 0; i < EST_NMID; ++i) stage[1 + i] = p + "mid_blocks." + S(i) + ".";
+    stage[EST_NRES - 1] = p + "up_blocks.0.";
+    std::vector<std::string> tw, tb;
+    for (int i = 0; i < EST_NRES; ++i) {
+      const std::string q = stage[i] + "0.";
+      const int cin = i == 0 ? EST_IN : (i == EST_NRES - 1 ? 2 * EST_CH : EST_CH);
+      tw.push_back(q + "mlp.1.weight");
+      tb.push_back(q + "mlp.1.bias");
+      e.res[i].block1 = pk.conv_named(q + "block1.block.0.", EST_CH, cin, 3);
+      e.res[i].ln1 = pk.ln(q + "block1.block.2.", "weight", "bias");
+      e.res[i].block2 = pk.conv_named(q + "block2.block.0.", EST_CH, EST_CH, 3);
+      e.res[i].ln2 = pk.ln(q + "block2.block.2.", "weight", "bias");
+      e.res[i].res = pk.linear(q + "res_conv.weight", q + "res_conv.bias", EST_CH, cin);
+      for (int j = 0; j < EST_NBLK; ++j) {
+        const std::string b = stage[i] + "1." + S(j) + ".";
+        BtbW& w = e.blk[i][j];
+        w.n1 = pk.ln(b + "norm1.", "weight", "bias");
+        w.qkv = pk.concat({b + "attn1.to_q.weight", b + "attn1.to_k.weight", b + "attn1.to_v.weight"}, {}, EST_INNER, EST_CH);
+        w.out = pk.linear(b + "attn1.to_out.0.weight", b + "attn1.to_out.0.bias", EST_CH, EST_INNER);
+        w.n3 = pk.ln(b + "norm3.", "weight", "bias");
+        w.ff1 = pk.linear(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", EST_FF, EST_CH);
+        w.ff2 = pk.linear(b + "ff.net.2.weight", b + "ff.net.2.bias", EST_CH, EST_FF);
+      }
+    }
+    e.temb_all = pk.concat(tw, tb, EST_CH, EST_TIME);
+    e.down_conv = pk.conv_named(p + "down_blocks.0.2.", EST_CH, EST_CH, 3);
+    e.up_conv = pk.conv_named(p + "up_blocks.0.2.", EST_CH, EST_CH, 3);
+    e.final_conv = pk.conv_named(p + "final_block.block.0.", EST_CH, EST_CH, 3);
+    e.final_ln = pk.ln(p + "final_block.block.2.", "weight", "bias");
+    e.final_proj = pk.linear(p + "final_proj.weight", p + "final_proj.bias", N_FEATS, EST_CH);
+
+    // ---------------- text encoder + duration predictor ----------------
+    EncoderW& n = c.enc;
+    const std::string q = "encoder.";
+    n.emb = pk.ptr(q + "emb.weight");
+    n.lang_emb = pk.ptr(q + "lang_emb.weight");
+    n.tone_emb = pk.ptr(q + "tone_emb.weight");
+    n.wpos_emb = pk.ptr(q + "word_pos_emb.weight");
+    n.spos_emb = pk.ptr(q + "syllable_pos.weight");
+    for (int i = 0; i < 3; ++i) {
+      n.pre_conv[i] = pk.conv_named(q + "prenet.conv_layers." + S(i) + ".", ENC_CH, ENC_CH, 5);
+      n.pre_ln[i] = pk.ln(q + "prenet.norm_layers." + S(i) + ".", "gamma", "beta");
+    }
+    n.pre_proj = pk.linear(q + "prenet.proj.weight", q + "prenet.proj.bias", ENC_CH, ENC_CH);
+    for (int i = 0; i < ENC_LAYERS; ++i) {
+      const std::string a = q + "encoder.attn_layers." + S(i) + ".";
+      EncLayerW& L = n.layer[i];
+      L.qkv = pk.concat({a + "conv_q.weight", a + "conv_k.weight", a + "conv_v.weight"},
+                        {a + "conv_q.bias", a + "conv_k.bias", a + "conv_v.bias"}, ENC_HID, ENC_HID);
+      L.o = pk.linear(a + "conv_o.weight", a + "conv_o.bias", ENC_HID, ENC_HID);
+      L.n1 = pk.ln(q + "encoder.norm_layers_1." + S(i) + ".", "gamma", "beta");
+      L.ffn1 = pk.conv_named(q + "encoder.ffn_layers." + S(i) + ".conv_1.", ENC_FILTER, ENC_HID, 3);
+      L.ffn2 = pk.conv_named(q + "encoder.ffn_layers." + S(i) + ".conv_2.", ENC_HID, ENC_FILTER, 3);
+      L.n2 = pk.ln(q + "encoder.norm_layers_2." + S(i) + ".", "gamma", "beta");
+    }
+    n.proj = pk.linear(q + "proj.weight", q + "proj.bias", N_FEATS, ENC_HID);
+    n.dp_cond = pk.linear("dp.cond.weight", "dp.cond.bias", ENC_HID, SPK_DIM);
+    n.dp_conv1 = pk.conv_named("dp.conv_1.", DP_FILTER, ENC_HID, 3);
+    n.dp_ln1 = pk.ln("dp.norm_1.", "gamma", "beta");
+    n.dp_conv2 = pk.conv_named("dp.conv_2.", DP_FILTER, DP_FILTER, 3);
+    n.dp_ln2 = pk.ln("dp.norm_2.", "gamma", "beta");
+    n.dp_proj = pk.linear("dp.proj.weight", "dp.proj.bias", 1, DP_FILTER);
+    n.spk_affine = pk.linear("spk_embed_affine_layer.weight", "spk_embed_affine_layer.bias", N_FEATS, SPK_DIM);
+  } else if (model == MODEL_HIFT) {
+    HiftW& h = c.hift;
+    for (int i = 0; i < 5; ++i) {
+      const std::string q = "f0_predictor.condnet." + S(2 * i) + ".";
+      const int cin = i == 0 ? N_FEATS : HIFT_F0_CH;
+      h.f0_conv[i] = pk.conv(pk.folded(q + "weight_g", q + "weight_v"), HIFT_F0_CH, cin, 3, i == 0 ? 96 : cin, pk.ptr(q + "bias"));
+    }
+    h.f0_cls_w = pk.ptr("f0_predictor.classifier.weight");
+    h.f0_cls_b = pk.ptr("f0_predictor.classifier.bias");
+    h.src_lin_w = pk.ptr("m_source.l_linear.weight");
+    h.src_lin_b = pk.ptr("m_source.l_linear.bias");
+    h.conv_pre = pk.conv_wn("conv_pre.", HIFT_CH, N_FEATS, 7, 96);
+    const int up_k[3] = {16, 11, 7}, up_s[3] = {8, 5, 3}, sd_k[3] = {30, 6, 1}, src_k[3] = {7, 7, 11}, rb_k[3] = {3, 7, 11};
+    for (int i = 0; i < 3; ++i) {
+      h.ups[i] = pk.convT_wn("ups." + S(i) + ".", HIFT_CH >> i, HIFT_CH >> (i + 1), up_k[i], up_s[i]);
+      // strided source conv as a GEMM over k*32 contiguous floats of the 32-column s_stft row buffer
+      GemmW sd = pk.conv_named("source_downs." + S(i) + ".", HIFT_CH >> (i + 1), HIFT_NFFT + 2, sd_k[i], 32);
+      sd.Cin = sd_k[i] * 32;
+      sd.ntaps = 1;
+      h.src_down[i] = sd;
+    }
+    auto resblock = [&](const std::string& q, int ch, int k) {
+      ResBlockW w;
+      w.k = k;
+      for (int j = 0; j < 3; ++j) {
+        w.c1[j] = pk.conv_wn(q + "convs1." + S(j) + ".", ch, ch, k);
+        w.c2[j] = pk.conv_wn(q + "convs2." + S(j) + ".", ch, ch, k);
+        w.a1[j] = pk.ptr(q + "activations1." + S(j) + ".alpha");
+        w.a2[j] = pk.ptr(q + "activations2." + S(j) + ".alpha");
+      }
+      return w;
+    };
+    for (int i = 0; i < 3; ++i) h.src_rb[i] = resblock("source_resblocks." + S(i) + ".", HIFT_CH >> (i + 1), src_k[i]);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) h.rb[3 * i + j] = resblock("resblocks." + S(3 * i + j) + ".", HIFT_CH >> (i + 1), rb_k[j]);
+    h.conv_post = pk.conv_wn("conv_post.", HIFT_NFFT + 2, HIFT_CH >> 3, 7);
+  } else {
+    return fail(JV_ERR_ARG, "finalize: unknown model id");
+  }
+  if (pk.rc != JV_OK) return pk.rc;
+  JV_HIP(hipGetLastError());
+  JV_HIP(hipStreamSynchronize(st));
+  c.ready[model] = true;
+  return JV_OK;
+}
+
+}  // namespace jv

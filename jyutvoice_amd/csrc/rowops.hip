@@ -1,0 +1,302 @@
+// Bandwidth-bound row-buffer kernels: LayerNorm, layout packing, the flow solver's glue.
+// All of them move 16 B per lane, one wave (or a few lanes) per row, rows contiguous in HBM.
+#include <math.h>
+
+#include "jv_common.h"
+#include "jv_ops.h"
+
+namespace jv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- LayerNorm over the channel axis of a row buffer (optionally of x + add) -------------------
+// One wave per row; two-pass (mean, then centred sum of squares) entirely in registers for C <= 1024.
+template <int VPL>   // f32x4 per lane
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                             float* __restrict__ out, const float* __restrict__ g,
+                                                             const float* __restrict__ b, float eps, long rows, int C,
+                                                             const unsigned char* __restrict__ rowmask_out) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c4n = C >> 2;
+  f32x4 v[VPL];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c4 = lane + 64 * i;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < c4n) {
+      t = *reinterpret_cast<const f32x4*>(x + row * C + 4 * c4);
+      if (add) t += *reinterpret_cast<const f32x4*>(add + row * C + 4 * c4);
+    }
+    v[i] = t;
+    sum += (t[0] + t[1]) + (t[2] + t[3]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < c4n) {
+      const f32x4 d = v[i] - mean;
+      sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+  const bool keep = !rowmask_out || rowmask_out[row];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < c4n) {
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * c4);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 4 * c4);
+      f32x4 r = (v[i] - mean) * rstd * gg + bb;
+      if (!keep) r = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(out + row * C + 4 * c4) = r;
+    }
+  }
+}
+
+int layernorm_rows(const float* x, const float* add, float* out, const float* g, const float* b, float eps, long rows,
+                   int C, const unsigned char* rowmask_out, hipStream_t st) {
+  if (rows <= 0) return JV_OK;
+  if (C & 3 || C > 1024) return fail(JV_ERR_ARG, "layernorm_rows: C must be a multiple of 4, <= 1024");
+  const dim3 grid((unsigned)cdivl(rows, 4));
+  if (C <= 256)
+    hipLaunchKernelGGL((layernorm_rows_kernel<1>), grid, dim3(256), 0, st, x, add, out, g, b, eps, rows, C, rowmask_out);
+  else if (C <= 768)
+    hipLaunchKernelGGL((layernorm_rows_kernel<3>), grid, dim3(256), 0, st, x, add, out, g, b, eps, rows, C, rowmask_out);
+  else
+    hipLaunchKernelGGL((layernorm_rows_kernel<4>), grid, dim3(256), 0, st, x, add, out, g, b, eps, rows, C, rowmask_out);
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+// ---- row metadata: rowmask[r] (1 = real frame) and row_sample[r] (utterance index) -----------------
+__global__ void row_meta_kernel(unsigned char* rowmask, int* row_sample, const int* lens, int nb, int reps, int G, int S,
+                                int L, long rows, int mul, int add) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const long rel = r - G;
+  int b = rel >= 0 ? (int)(rel / S) : 0;
+  const int t = rel >= 0 ? (int)(rel - (long)b * S) : -1;
+  const int B = nb * reps;
+  bool ok = rel >= 0 && b < B && t < L;
+  if (b >= B) b = B - 1;
+  if (ok && lens) ok = t < lens[b % nb] * mul + add;
+  rowmask[r] = ok ? 1 : 0;
+  if (row_sample) row_sample[r] = b;
+}
+
+int row_meta(unsigned char* rowmask, int* row_sample, const int* lens, int nb, int reps, int G, int S, int L, long rows,
+             int mul, int add, hipStream_t st) {
+  hipLaunchKernelGGL(row_meta_kernel, dim3((unsigned)cdivl(rows, 256)), dim3(256), 0, st, rowmask, row_sample, lens, nb,
+                     reps, G, S, L, rows, mul, add);
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+// ---- channels-first [B,C,T] <-> row buffer [G + b*S + t][ld] (LDS-tiled transpose) ----------------
+__global__ __launch_bounds__(256) void cf_to_rows_kernel(const float* __restrict__ src, long src_bstride, long pitch, int C,
+                                                         int T, float* __restrict__ dst, int ld, int col0, int G, int S,
+                                                         float scale, const int* __restrict__ lens) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int tmax = lens ? min(lens[b], T) : T;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, t = t0 + tx;
+    tile[ty + 8 * i][tx] = (c < C && t < tmax) ? src[b * src_bstride + (long)c * pitch + t] * scale : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + ty + 8 * i, c = c0 + tx;
+    if (t < T && c < C) dst[((long)G + (long)b * S + t) * ld + col0 + c] = tile[tx][ty + 8 * i];
+  }
+}
+
+int cf_to_rows(const float* src, long src_bstride, long pitch, int B, int C, int T, float* dst, int ld, int col0, int G,
+               int S, float scale, const int* lens, hipStream_t st) {
+  if (B <= 0 || T <= 0) return JV_OK;
+  hipLaunchKernelGGL(cf_to_rows_kernel, dim3(cdiv(T, 32), cdiv(C, 32), B), dim3(256), 0, st, src, src_bstride, pitch, C, T,
+                     dst, ld, col0, G, S, scale, lens);
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+__global__ __launch_bounds__(256) void rows_to_cf_kernel(const float* __restrict__ src, int ld, int col0, int G, int S,
+                                                         float* __restrict__ dst, long dst_bstride, int C, int T,
+                                                         const int* __restrict__ lens) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int tmax = lens ? min(lens[b], T) : T;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (t < tmax && c < C) ? src[((long)G + (long)b * S + t) * ld + col0 + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, t = t0 + tx;
+    if (c < C && t < T) dst[b * dst_bstride + (long)c * T + t] = tile[tx][ty + 8 * i];
+  }
+}
+
+int rows_to_cf(const float* src, int ld, int col0, int G, int S, float* dst, long dst_bstride, int B, int C, int T,
+               const int* lens, hipStream_t st) {
+  if (B <= 0 || T <= 0) return JV_OK;
+  hipLaunchKernelGGL(rows_to_cf_kernel, dim3(cdiv(T, 32), cdiv(C, 32), B), dim3(256), 0, st, src, ld, col0, G, S, dst,
+                     dst_bstride, C, T, lens);
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+// ---- flow estimator input: [x | mu | spks | cond] per row, CFG rows appended ---------------------------
+// rows of utterance b' < B are conditional; b' >= B are the unconditional twin of b' - B (mu = spks = cond = 0),
+// jyutvoice/flow/flow_matching.py:246-251.  x/mu/cond are row buffers of 80 columns with geometry (G,S).
+__global__ __launch_bounds__(256) void assemble_xin_kernel(const float* __restrict__ x, const float* __restrict__ mu,
+                                                           const float* __restrict__ spks, const float* __restrict__ cond,
+                                                           float* __restrict__ xin, int B, int G, int S, int L, long rows2) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // one f32x4 (4 of 320 columns) per thread
+  const long r = idx / 80;
+  const int c4 = (int)(idx - r * 80);
+  if (r >= rows2) return;
+  const long rel = r - G;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (rel >= 0) {
+    const int b2 = (int)(rel / S);
+    const int t = (int)(rel - (long)b2 * S);
+    if (b2 < 2 * B && t < L) {
+      const bool un = b2 >= B;
+      const int b = un ? b2 - B : b2;
+      const long sr = (long)G + (long)b * S + t;
+      const int part = c4 / 20, cc = (c4 % 20) * 4;
+      if (part == 0) v = *reinterpret_cast<const f32x4*>(x + sr * 80 + cc);
+      else if (!un) {
+        if (part == 1) v = *reinterpret_cast<const f32x4*>(mu + sr * 80 + cc);
+        else if (part == 2) v = *reinterpret_cast<const f32x4*>(spks + b * 80 + cc);
+        else v = *reinterpret_cast<const f32x4*>(cond + sr * 80 + cc);
+      }
+    }
+  }
+  *reinterpret_cast<f32x4*>(xin + r * 320 + 4 * c4) = v;
+}
+
+int assemble_xin(const float* x, const float* mu, const float* spks, const float* cond, float* xin, int B, int G, int S,
+                 int L, long rows2, hipStream_t st) {
+  hipLaunchKernelGGL(assemble_xin_kernel, dim3((unsigned)cdivl(rows2 * 80, 256)), dim3(256), 0, st, x, mu, spks, cond, xin,
+                     B, G, S, L, rows2);
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+// generic variant for jv_flow_estimator_step (caller supplies all 2B rows, nothing implied zero)
+__global__ __launch_bounds__(256) void assemble_xin_plain_kernel(const float* __restrict__ x, const float* __restrict__ mu,
+                                                                 const float* __restrict__ spks,
+                                                                 const float* __restrict__ cond, float* __restrict__ xin,
+                                                                 int B, int G, int S, int L, long rows) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long r = idx / 80;
+  const int c4 = (int)(idx - r * 80);
+  if (r >= rows) return;
+  const long rel = r - G;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (rel >= 0) {
+    const int b = (int)(rel / S);
+    const int t = (int)(rel - (long)b * S);
+    if (b < B && t < L) {
+      const int part = c4 / 20, cc = (c4 % 20) * 4;
+      if (part == 0) v = *reinterpret_cast<const f32x4*>(x + r * 80 + cc);
+      else if (part == 1) v = *reinterpret_cast<const f32x4*>(mu + r * 80 + cc);
+      else if (part == 2) v = *reinterpret_cast<const f32x4*>(spks + b * 80 + cc);
+      else v = *reinterpret_cast<const f32x4*>(cond + r * 80 + cc);
+    }
+  }
+  *reinterpret_cast<f32x4*>(xin + r * 320 + 4 * c4) = v;
+}
+
+int assemble_xin_plain(const float* x, const float* mu, const float* spks, const float* cond, float* xin, int B, int G,
+                       int S, int L, long rows, hipStream_t st) {
+  hipLaunchKernelGGL(assemble_xin_plain_kernel, dim3((unsigned)cdivl(rows * 80, 256)), dim3(256), 0, st, x, mu, spks, cond,
+                     xin, B, G, S, L, rows);
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+// ---- sinusoidal timestep embedding (jyutvoice/flow/decoder.py:21-30), 320 = 160 sin | 160 cos ------------
+__global__ void time_sinusoid_kernel(const float* __restrict__ t, int t_stride, float* __restrict__ out, int B) {
+  const int b = blockIdx.x, j = threadIdx.x;   // 160 threads
+  if (b >= B || j >= 160) return;
+  const float c = (float)(-9.210340371976184 / 159.0);     // -(ln 10000)/(half-1), rounded to f32 like torch
+  const float f = expf((float)j * c);
+  const float a = (1000.0f * t[b * t_stride]) * f;
+  out[b * 320 + j] = sinf(a);
+  out[b * 320 + 160 + j] = cosf(a);
+}
+
+int time_sinusoid(const float* t, int t_stride, float* out, int B, hipStream_t st) {
+  hipLaunchKernelGGL(time_sinusoid_kernel, dim3(B), dim3(192), 0, st, t, t_stride, out, B);
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+// ---- Euler step with classifier-free guidance: x += dt * ((1+r) d_cond - r d_uncond) ----------------------
+// d holds 2B utterances (geometry G,S); step scalars come from a device table so the loop never syncs.
+__global__ __launch_bounds__(256) void euler_cfg_kernel(float* __restrict__ x, const float* __restrict__ d, int B, int G, int S,
+                                                        int L, const float* __restrict__ dt_table, int step, float rate) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // f32x4 index over B*L*20
+  const long per_b = (long)L * 20;
+  if (idx >= per_b * B) return;
+  const int b = (int)(idx / per_b);
+  const long rem = idx - (long)b * per_b;
+  const long r = (long)G + (long)b * S + rem / 20;
+  const int cc = (int)(rem % 20) * 4;
+  const float dt = dt_table[step];
+  const f32x4 dc = *reinterpret_cast<const f32x4*>(d + r * 80 + cc);
+  const f32x4 du = *reinterpret_cast<const f32x4*>(d + (r + (long)B * S) * 80 + cc);
+  f32x4 xv = *reinterpret_cast<f32x4*>(x + r * 80 + cc);
+  const f32x4 g = (1.0f + rate) * dc - rate * du;
+  xv = xv + dt * g;
+  *reinterpret_cast<f32x4*>(x + r * 80 + cc) = xv;
+}
+
+int euler_cfg(float* x, const float* d, int B, int G, int S, int L, const float* dt_table, int step, float rate,
+              hipStream_t st) {
+  hipLaunchKernelGGL(euler_cfg_kernel, dim3((unsigned)cdivl((long)B * L * 20, 256)), dim3(256), 0, st, x, d, B, G, S, L,
+                     dt_table, step, rate);
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+__global__ void fill_int_kernel(int* p, int v, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+int fill_int(int* p, int v, long n, hipStream_t st) {
+  if (n <= 0) return JV_OK;
+  hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, p, v, n);
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+__global__ void fill_kernel(float* p, float v, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+int fill(float* p, float v, long n, hipStream_t st) {
+  if (n <= 0) return JV_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, p, v, n);
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+}  // namespace jv

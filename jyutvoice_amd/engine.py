@@ -1,0 +1,207 @@
+"""Thin host wrapper around one libjyutvoice_hip context.
+
+PyTorch is plumbing only: it owns the device buffers handed to the C ABI (raw `data_ptr()`s) and the
+stream they are enqueued on.  Every numerical step of the hot path runs inside the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib, spec
+from ._lib import JV_MODEL_HIFT, JV_MODEL_TTS, JvError, check
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class Engine:
+    """One library context = packed weights + workspace for up to `max_batch` utterances of
+    `max_frames` mel frames / `max_tokens` tokens, bound to one GPU."""
+
+    def __init__(self, device="cuda:0", max_batch=1, max_frames=2048, max_tokens=512):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("jyutvoice_amd runs on an AMD GPU only (device must be cuda:N); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible to PyTorch-ROCm; jyutvoice_amd has no CPU path")
+        self.max_batch, self.max_frames, self.max_tokens = max_batch, max_frames, max_tokens
+        h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        check(self.lib.jv_create(C.byref(h), idx, max_batch, max_frames, max_tokens))
+        self._h = h
+        self._loaded = {JV_MODEL_TTS: False, JV_MODEL_HIFT: False}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.jv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- registry ---------------------------------------------------------------------------------
+    def registry(self, model: int) -> Dict[str, tuple]:
+        out = {}
+        for i in range(self.lib.jv_num_tensors(self._h)):
+            if self.lib.jv_tensor_model(self._h, i) != model:
+                continue
+            nd = self.lib.jv_tensor_ndim(self._h, i)
+            out[self.lib.jv_tensor_name(self._h, i).decode()] = tuple(
+                int(self.lib.jv_tensor_dim(self._h, i, d)) for d in range(nd))
+        return out
+
+    # ---- weights ----------------------------------------------------------------------------------
+    def load_state_dict(self, model: int, sd: Dict[str, torch.Tensor], strict: bool = True):
+        """Mirror of nn.Module.load_state_dict for the library's registry: same missing/unexpected-key
+        semantics; shapes are checked by the library (RuntimeError on mismatch, like torch)."""
+        expected = self.registry(model)
+        missing = [k for k in expected if k not in sd]
+        unexpected = [k for k in sd if k not in expected]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: Missing key(s): {missing[:8]}{'...' if len(missing) > 8 else ''}; "
+                               f"Unexpected key(s): {unexpected[:8]}{'...' if len(unexpected) > 8 else ''}")
+        st = _stream(self.device)
+        for k in expected:
+            if k not in sd:
+                continue
+            t = _f32(sd[k].detach(), self.device)
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            try:
+                check(self.lib.jv_load_tensor(self._h, k.encode(), _ptr(t), shape, t.dim(), 1, st))
+            except JvError as e:
+                raise RuntimeError(e.msg) from None
+        torch.cuda.synchronize(self.device)
+        if not missing:
+            check(self.lib.jv_finalize(self._h, model, st))
+            self._loaded[model] = True
+        return missing, unexpected
+
+    def load_noise(self, noise: torch.Tensor):
+        t = _f32(noise, self.device)
+        check(self.lib.jv_load_noise(self._h, _ptr(t), t.numel(), 1, _stream(self.device)))
+        torch.cuda.synchronize(self.device)
+
+    # ---- flow ---------------------------------------------------------------------------------------
+    def flow_estimator(self, x, mask_lens, mu, t, spks, cond):
+        """[B2,80,T] tensors on the device; mask_lens int32 [B2] or None."""
+        B2, _, T = x.shape
+        x, mu, cond = (_f32(v, self.device) for v in (x, mu, cond))
+        t, spks = _f32(t, self.device), _f32(spks, self.device)
+        lens = None if mask_lens is None else mask_lens.to(device=self.device, dtype=torch.int32).contiguous()
+        out = torch.empty_like(x)
+        check(self.lib.jv_flow_estimator_step(self._h, _ptr(x), _ptr(lens), _ptr(mu), _ptr(t), _ptr(spks), _ptr(cond), B2, T,
+                                              _ptr(out), _stream(self.device)))
+        return out
+
+    def cfm_solve(self, mu, lens, spks, cond, n_timesteps, temperature=1.0, t_span=None):
+        B, _, T = mu.shape
+        mu, cond, spks = _f32(mu, self.device), _f32(cond, self.device), _f32(spks, self.device)
+        lens_d = None if lens is None else lens.to(device=self.device, dtype=torch.int32).contiguous()
+        mel = torch.empty_like(mu)
+        ts = None
+        if t_span is not None:
+            ts_host = t_span.detach().to("cpu", torch.float32).contiguous()
+            ts = (C.c_float * ts_host.numel())(*ts_host.tolist())
+        check(self.lib.jv_cfm_solve(self._h, _ptr(mu), _ptr(lens_d), _ptr(spks), _ptr(cond), B, T, int(n_timesteps),
+                                    float(temperature), ts, _ptr(mel), _stream(self.device)))
+        return mel
+
+    # ---- encoder --------------------------------------------------------------------------------------
+    def encoder(self, x, x_lengths, lang, tone, word_pos, syllable_pos, spk_embed):
+        B, Tt = x.shape
+        ids = [v.to(device=self.device, dtype=torch.int64).contiguous() for v in (x, lang, tone, word_pos, syllable_pos)]
+        xl = x_lengths.to(device=self.device, dtype=torch.int64).contiguous()
+        spk = _f32(spk_embed, self.device)
+        h = torch.empty(B, spec.ENC_HIDDEN, Tt, device=self.device)
+        mu_x = torch.empty(B, spec.N_FEATS, Tt, device=self.device)
+        logw = torch.empty(B, 1, Tt, device=self.device)
+        c = torch.empty(B, spec.N_FEATS, device=self.device)
+        check(self.lib.jv_encoder_fwd(self._h, *[_ptr(v) for v in ids], _ptr(xl), _ptr(spk), B, Tt, _ptr(h), _ptr(mu_x),
+                                      _ptr(logw), _ptr(c), _stream(self.device)))
+        return h, mu_x, logw, c
+
+    def length_regulate(self, logw, x_lengths, mu_x, length_scale=1.0):
+        B, _, Tt = logw.shape
+        xl = x_lengths.to(device=self.device, dtype=torch.int64).contiguous()
+        w_ceil = torch.empty(B, 1, Tt, device=self.device)
+        y_lengths = torch.empty(B, dtype=torch.int64, device=self.device)
+        st = _stream(self.device)
+        check(self.lib.jv_length_regulate(self._h, _ptr(logw), _ptr(xl), _ptr(mu_x), B, Tt, float(length_scale), _ptr(w_ceil),
+                                          _ptr(y_lengths), 0, None, None, st))
+        ty = int(y_lengths.max().item())       # the reference's one host sync (jyutvoice_tts.py:187)
+        attn = torch.empty(B, Tt, ty, device=self.device)
+        mu_y = torch.empty(B, spec.N_FEATS, ty, device=self.device)
+        check(self.lib.jv_length_regulate(self._h, _ptr(logw), _ptr(xl), _ptr(mu_x), B, Tt, float(length_scale), _ptr(w_ceil),
+                                          _ptr(y_lengths), ty, _ptr(attn), _ptr(mu_y), st))
+        return w_ceil, y_lengths, attn, mu_y
+
+    # ---- HiFT -----------------------------------------------------------------------------------------
+    def hift_f0(self, mel, lens=None):
+        B, _, T = mel.shape
+        mel = _f32(mel, self.device)
+        lens_d = None if lens is None else lens.to(device=self.device, dtype=torch.int32).contiguous()
+        f0 = torch.empty(B, T, device=self.device)
+        check(self.lib.jv_hift_f0(self._h, _ptr(mel), _ptr(lens_d), B, T, _ptr(f0), _stream(self.device)))
+        return f0
+
+    def hift_source(self, f0, phase, noise):
+        B, T = f0.shape
+        f0, phase, noise = _f32(f0, self.device), _f32(phase, self.device), _f32(noise, self.device)
+        s = torch.empty(B, 1, T * spec.HIFT_UPSAMPLE_TOTAL, device=self.device)
+        check(self.lib.jv_hift_source(self._h, _ptr(f0), _ptr(phase), _ptr(noise), B, T, _ptr(s), _stream(self.device)))
+        return s
+
+    def hift_decode(self, mel, s, lens=None):
+        B, _, T = mel.shape
+        mel, s = _f32(mel, self.device), _f32(s, self.device)
+        lens_d = None if lens is None else lens.to(device=self.device, dtype=torch.int32).contiguous()
+        wav = torch.empty(B, T * spec.HIFT_UPSAMPLE_TOTAL, device=self.device)
+        check(self.lib.jv_hift_decode(self._h, _ptr(mel), _ptr(s), _ptr(lens_d), B, T, _ptr(wav), _stream(self.device)))
+        return wav
+
+
+# ---- operator-level helpers for the parity tests (same kernels the stages launch) ------------------------
+def op_conv_gemm(A, W, bias=None, ntaps=1, tap_row0=0, dil=1, M=None, act="none", prologue="none", alpha=None, slope=0.0,
+                 ln=None, ln_eps=1e-5, rowmask=None, res=None):
+    """A [rows, Cin] cuda fp32; W [N, ntaps*Cin]; returns out [M, N]."""
+    lib = _lib.load()
+    rows, cin = A.shape
+    N = W.shape[0]
+    M = rows if M is None else M
+    out = torch.empty(M, N, device=A.device)
+    g, b = (ln if ln is not None else (None, None))
+    check(lib.jv_op_conv_gemm(_ptr(A), rows, M, cin, ntaps, tap_row0, dil, _ptr(W), N, _ptr(bias), _lib.ACT[act],
+                              _lib.PRO[prologue], _ptr(alpha), float(slope), _ptr(g), _ptr(b), float(ln_eps), _ptr(rowmask),
+                              _ptr(res), _ptr(out), _stream(A.device)))
+    return out
+
+
+def op_attention(qkv, lens, B, G, S, L):
+    lib = _lib.load()
+    out = torch.zeros(qkv.shape[0], 512, device=qkv.device)
+    check(lib.jv_op_attention(_ptr(qkv), _ptr(lens), B, G, S, L, _ptr(out), _stream(qkv.device)))
+    return out
+
+
+def op_layernorm(x, g, b, eps=1e-5):
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    check(lib.jv_op_layernorm(_ptr(x), _ptr(g), _ptr(b), float(eps), x.shape[0], x.shape[1], _ptr(out), _stream(x.device)))
+    return out

@@ -1,0 +1,148 @@
+"""GPU: operator-level parity of the HIP kernels (called through the C ABI) against fp64 PyTorch on the CPU."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
+    return torch.device("cuda:0")
+
+
+def pack_conv(w):
+    """[Cout, Cin, k] -> [Cout, k*Cin] tap-major (the library's GEMM operand layout)"""
+    return w.permute(0, 2, 1).reshape(w.shape[0], -1).contiguous()
+
+
+def conv_rows_ref(A, w, bias, tap_row0, dil):
+    """reference for the row-buffer conv: out[m] = sum_j A[m + tap_row0 + j*dil] @ w[:, :, j].T, zero outside"""
+    A = A.double()
+    w = w.double()
+    rows = A.shape[0]
+    out = torch.zeros(rows, w.shape[0], dtype=torch.float64)
+    for j in range(w.shape[2]):
+        off = tap_row0 + j * dil
+        src = torch.zeros_like(A)
+        lo, hi = max(0, -off), min(rows, rows - off)
+        if hi > lo:
+            src[lo:hi] = A[lo + off:hi + off]
+        out += src @ w[:, :, j].T
+    if bias is not None:
+        out += bias.double()
+    return out
+
+
+def rel_err(got, want):
+    return float((got.double().cpu() - want).abs().max() / (want.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 256, 1536), (19, 1024, 256), (2, 320, 1024), (1000, 512, 80), (129, 256, 18),
+                                   (4100, 256, 256)])
+def test_linear(dev, M, K, N):
+    from jyutvoice_amd.engine import op_conv_gemm
+    g = torch.Generator().manual_seed(M + K + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    out = op_conv_gemm(A.to(dev), W.to(dev), b.to(dev))
+    want = A.double() @ W.double().T + b.double()
+    assert rel_err(out, want) < 2e-6
+
+
+@pytest.mark.parametrize("act", ["relu", "gelu", "mish", "elu", "silu"])
+def test_activations(dev, act):
+    from jyutvoice_amd.engine import op_conv_gemm
+    g = torch.Generator().manual_seed(7)
+    A = torch.randn(200, 64, generator=g) * 2
+    W = torch.randn(96, 64, generator=g) / 4
+    out = op_conv_gemm(A.to(dev), W.to(dev), None, act=act)
+    z = A.double() @ W.double().T
+    want = {"relu": torch.relu, "gelu": F.gelu, "mish": F.mish, "elu": F.elu, "silu": F.silu}[act](z)
+    assert float((out.double().cpu() - want).abs().max()) < 5e-6
+
+
+def test_causal_conv_ln_mish_mask(dev):
+    from jyutvoice_amd.engine import op_conv_gemm
+    g = torch.Generator().manual_seed(11)
+    rows, cin = 333, 320
+    A = torch.randn(rows, cin, generator=g)
+    w = torch.randn(256, cin, 3, generator=g) / math.sqrt(3 * cin)
+    b = torch.randn(256, generator=g) * 0.1
+    lg, lb = 1 + 0.1 * torch.randn(256, generator=g), 0.1 * torch.randn(256, generator=g)
+    mask = (torch.rand(rows, generator=g) > 0.2).to(torch.uint8)
+    res = torch.randn(rows, 256, generator=g)
+    out = op_conv_gemm(A.to(dev), pack_conv(w).to(dev), b.to(dev), ntaps=3, tap_row0=-2, act="mish",
+                       ln=(lg.to(dev), lb.to(dev)), rowmask=mask.to(dev), res=res.to(dev))
+    z = conv_rows_ref(A * mask[:, None], w, b, -2, 1)
+    z = F.layer_norm(z, (256,), lg.double(), lb.double(), 1e-5)
+    want = F.mish(z) * mask[:, None].double() + res.double()
+    assert float((out.double().cpu() - want).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("k,dil,C", [(11, 5, 64), (7, 3, 128), (3, 1, 256), (5, 1, 192)])
+def test_dilated_conv_snake_residual(dev, k, dil, C):
+    from jyutvoice_amd.engine import op_conv_gemm
+    g = torch.Generator().manual_seed(k * 100 + dil)
+    rows = 700
+    A = torch.randn(rows, C, generator=g)
+    w = torch.randn(C, C, k, generator=g) / math.sqrt(k * C)
+    b = torch.randn(C, generator=g) * 0.1
+    alpha = 1 + 0.1 * torch.randn(C, generator=g).abs()
+    res = torch.randn(rows, C, generator=g)
+    pad = dil * (k - 1) // 2
+    out = op_conv_gemm(A.to(dev), pack_conv(w).to(dev), b.to(dev), ntaps=k, tap_row0=-pad, dil=dil, prologue="snake",
+                       alpha=alpha.to(dev), res=res.to(dev))
+    Ad = A.double()
+    sn = Ad + (1.0 / (alpha.double() + 1e-9)) * torch.sin(Ad * alpha.double()) ** 2
+    want = conv_rows_ref(sn, w, b, -pad, dil) + res.double()
+    assert float((out.double().cpu() - want).abs().max()) < 2e-5
+    # same thing expressed as torch's own conv1d (ties the row-offset convention to F.conv1d's padding)
+    want2 = F.conv1d(sn.T[None], w.double(), b.double(), dilation=dil, padding=pad)[0].T + res.double()
+    assert float((want - want2).abs().max()) < 1e-9
+
+
+def test_lrelu_prologue(dev):
+    from jyutvoice_amd.engine import op_conv_gemm
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(130, 96, generator=g)
+    w = torch.randn(512, 96, 7, generator=g) / math.sqrt(7 * 96)
+    out = op_conv_gemm(A.to(dev), pack_conv(w).to(dev), None, ntaps=7, tap_row0=-3, prologue="lrelu", slope=0.1)
+    want = conv_rows_ref(F.leaky_relu(A.double(), 0.1), w, None, -3, 1)
+    assert float((out.double().cpu() - want).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("B,L,lens", [(3, 77, [77, 40, 1]), (2, 300, [300, 257]), (1, 512, [512]), (2, 33, [33, 32])])
+def test_attention(dev, B, L, lens):
+    from jyutvoice_amd.engine import op_attention
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    G, gap = 4, 4
+    S = L + gap
+    rows = G + B * S + 8
+    qkv = torch.randn(rows, 1536, generator=g)
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    out = op_attention(qkv.to(dev), lens_t.to(dev), B, G, S, L).cpu()
+    for b in range(B):
+        blk = qkv[G + b * S: G + b * S + L].double()
+        q, k, v = (blk[:, i * 512:(i + 1) * 512].view(L, 8, 64).transpose(0, 1) for i in range(3))
+        s = q @ k.transpose(1, 2) / 8.0
+        s[:, :, lens[b]:] = -1e10
+        o = (torch.softmax(s, -1) @ v).transpose(0, 1).reshape(L, 512)
+        got = out[G + b * S: G + b * S + L].double()
+        assert float((got - o).abs().max()) < 5e-6, b
+
+
+@pytest.mark.parametrize("C,eps", [(256, 1e-5), (576, 1e-4), (192, 1e-4)])
+def test_layernorm(dev, C, eps):
+    from jyutvoice_amd.engine import op_layernorm
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(1001, C, generator=g) * 3 + 1
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    out = op_layernorm(x.to(dev), w.to(dev), b.to(dev), eps)
+    want = F.layer_norm(x.double(), (C,), w.double(), b.double(), eps)
+    assert float((out.double().cpu() - want).abs().max()) < 1e-5
