@@ -37,9 +37,6 @@ void enc_ws_destroy(Context& c);
 
 using jv::Context;
 
-struct jv_context {
-  Context c;
-};
 
 #define CTX_GUARD(ctx)                                                       \
   if (!(ctx)) return jv::fail(JV_ERR_ARG, "null context");                   \

@@ -1,12 +1,263 @@
-// placeholder replaced below
+// HiFT vocoder stage (jyutvoice/hifigan/generator.py:396-466, f0_predictor.py:52-55) on row buffers.
+//
+// Four time resolutions share one geometry derived from the mel level (guard G0 = gap = 4 frames):
+//   level 0 (mel, T)      rows r0            = 4   + b*(T+4) + t
+//   level 1 (x8)          rows 8  r0 + phase = 32  + b*8(T+4)   + t
+//   level 2 (x40)         rows 40 r0 + phase = 160 + b*40(T+4)  + t
+//   level 3 (x120, +1)    rows               = 479 + b*120(T+4) + tau      (tau = t+1 after ReflectionPad1d((1,0)))
+// so a polyphase ConvTranspose1d maps input row r to output rows s*r .. s*r+s-1 with no index arithmetic, the
+// strided source convs are GEMMs over contiguous spans of the 32-column STFT row buffer (row stride 15*32 / 3*32), and
+// the gaps (>= 25 rows at every level) are the zero padding of every dilated ResBlock convolution.
+// Snake / LeakyReLU run in the conv kernel's prologue, bias / residual / x+si fusion / MRF mean in its epilogue.
 #include "../../include/jyutvoice_hip.h"
 #include "jv_model.h"
+#include "jv_ops.h"
+
 namespace jv {
-int hift_ws_create(Context&) { return JV_OK; }
-void hift_ws_destroy(Context&) {}
+
+int f0_head(const float* h, const float* w, const float* bias, float* f0, int B, int T, int G, int S, hipStream_t st);
+int sine_source(const float* f0, const float* phase, const float* noise, const float* lin_w, const float* lin_b, float* frac,
+                float* s, int B, int T, hipStream_t st);
+int stft_rows(const float* s, float* out, const int* lens, int B, int T, int G3, int S3, long rows, hipStream_t st);
+int reflect_fix(float* x, int B, int G3, int S3, int C, hipStream_t st);
+int istft_head(const float* post, float* frames, float* wav, const int* lens, int B, int T, int G3, int S3, long rows,
+               hipStream_t st);
+
+constexpr int H_G0 = 4, H_GAP0 = 4;
+constexpr int UPS[3] = {8, 5, 3};
+constexpr int LVL_MUL[4] = {1, 8, 40, 120};
+
+struct HiftWs {
+  long rows0_alloc = 0;
+  float* mel = nullptr;                      // [rows0, 96]
+  float *f0a = nullptr, *f0b = nullptr;      // [rows0, 512]
+  float* x0 = nullptr;                       // [rows0, 512] conv_pre output
+  float *x[3] = {}, *r[3] = {}, *tmp[3] = {}, *xs[3] = {}, *si[3] = {};   // per level 1..3: [rows_l, C_l]
+  float* stft_alloc = nullptr;               // [16 + rows3 + 16, 32]
+  float* post = nullptr;                     // [rows3, 32]
+  float* frames = nullptr;                   // [rows3, 16]
+  float* frac = nullptr;                     // [B, 9, 480 T]
+  unsigned char* mask[4] = {};
+  int* lens = nullptr;
+};
+
+int hift_ws_create(Context& c) {
+  HiftWs* w = new HiftWs();
+  c.hws = w;
+  const long rows0 = H_G0 + (long)c.max_batch * (c.max_frames + H_GAP0);
+  w->rows0_alloc = rows0 + 8;
+  const size_t R0 = (size_t)w->rows0_alloc;
+  auto F = [&](float** p, size_t floats) { return ws_alloc(c, floats * sizeof(float), reinterpret_cast<void**>(p)); };
+  JV_TRY(F(&w->mel, R0 * 96));
+  JV_TRY(F(&w->f0a, R0 * 512));
+  JV_TRY(F(&w->f0b, R0 * 512));
+  JV_TRY(F(&w->x0, R0 * 512));
+  for (int l = 0; l < 3; ++l) {
+    const size_t R = R0 * LVL_MUL[l + 1];
+    const int C = HIFT_CH >> (l + 1);
+    JV_TRY(F(&w->x[l], R * C));
+    JV_TRY(F(&w->r[l], R * C));
+    JV_TRY(F(&w->tmp[l], R * C));
+    JV_TRY(F(&w->xs[l], R * C));
+    JV_TRY(F(&w->si[l], R * C));
+  }
+  const size_t R3 = R0 * 120;
+  JV_TRY(F(&w->stft_alloc, (R3 + 32) * 32));
+  JV_TRY(F(&w->post, R3 * 32));
+  JV_TRY(F(&w->frames, R3 * 16));
+  JV_TRY(F(&w->frac, (size_t)c.max_batch * 9 * 480 * c.max_frames));
+  for (int l = 0; l < 4; ++l) JV_TRY(ws_alloc(c, R0 * LVL_MUL[l], reinterpret_cast<void**>(&w->mask[l])));
+  JV_TRY(ws_alloc(c, sizeof(int) * c.max_batch, reinterpret_cast<void**>(&w->lens)));
+  return JV_OK;
 }
+
+void hift_ws_destroy(Context& c) {
+  delete c.hws;
+  c.hws = nullptr;
+}
+
+namespace {
+
+struct HGeo {
+  int B, T, S0;
+  long rows[4];      // rows computed at each level
+  long alloc[4];     // rows readable at each level
+  int G[4], S[4], L[4];
+};
+
+HGeo make_geo(const Context& c, int B, int T) {
+  HGeo g;
+  g.B = B; g.T = T; g.S0 = T + H_GAP0;
+  const long rows0 = H_G0 + (long)B * g.S0;
+  for (int l = 0; l < 4; ++l) {
+    g.rows[l] = rows0 * LVL_MUL[l];
+    g.alloc[l] = c.hws->rows0_alloc * LVL_MUL[l];
+    g.S[l] = g.S0 * LVL_MUL[l];
+    g.G[l] = H_G0 * LVL_MUL[l];
+    g.L[l] = T * LVL_MUL[l];
+  }
+  g.G[3] = 479;          // tau = 0 sits one row before the natural x120 position
+  g.L[3] = 120 * T + 1;
+  return g;
+}
+
+int check(Context& c, int B, int T) {
+  if (!c.ready[MODEL_HIFT]) return fail(JV_ERR_STATE, "hift weights not finalized");
+  if (B < 1 || T < 1) return fail(JV_ERR_ARG, "batch and frame count must be positive");
+  if (B > c.max_batch || T > c.max_frames) return fail(JV_ERR_SHAPE, "batch/frames exceed the capacity given to jv_create");
+  return JV_OK;
+}
+
+ConvGemmArgs conv_args(const float* A, int lda, long a_rows, long M, const GemmW& w, float* out, int ldo, int tap_row0,
+                       int dil, const unsigned char* mask_in) {
+  ConvGemmArgs a;
+  conv_gemm_defaults(a);
+  a.A = A; a.lda = lda; a.a_rows = a_rows; a.M = (int)M;
+  a.Cin = w.Cin; a.ntaps = w.ntaps; a.tap_row0 = tap_row0; a.tap_dil = dil;
+  a.W = w.w; a.ldw = w.ldw; a.n_rows_w = w.n_rows; a.N = w.N; a.bias = w.bias;
+  a.out = out; a.ldo = ldo;
+  a.rowmask_in = mask_in;
+  return a;
+}
+
+// lens (device int32 [B] or null) -> ws.lens + the four row masks
+int prepare_masks(Context& c, const HGeo& g, const int* lens, hipStream_t st) {
+  HiftWs& w = *c.hws;
+  if (lens) JV_HIP(hipMemcpyAsync(w.lens, lens, sizeof(int) * g.B, hipMemcpyDeviceToDevice, st));
+  else JV_TRY(fill_int(w.lens, g.T, g.B, st));
+  for (int l = 0; l < 4; ++l)
+    JV_TRY(row_meta(w.mask[l], nullptr, w.lens, g.B, 1, g.G[l], g.S[l], g.L[l], g.alloc[l], LVL_MUL[l], l == 3 ? 1 : 0, st));
+  return JV_OK;
+}
+
+int mel_to_rows(Context& c, const HGeo& g, const float* mel, hipStream_t st) {
+  return cf_to_rows(mel, 80L * g.T, g.T, g.B, 80, g.T, c.hws->mel, 96, 0, H_G0, g.S0, 1.f, c.hws->lens, st);
+}
+
+// ResBlock (generator.py:90-97) of kernel k on [rows, C]: cur -> (result scaled/accumulated into dst, + extra residual)
+int resblock(const ResBlockW& rb, int C, long rows, long alloc, const unsigned char* mask, const float* cur, float* r,
+             float* tmp, float* dst, const float* extra_res, float scale, int accumulate, hipStream_t st) {
+  const int dils[3] = {1, 3, 5};
+  const float* in = cur;
+  for (int j = 0; j < 3; ++j) {
+    const int k = rb.k, d = dils[j];
+    ConvGemmArgs a = conv_args(in, C, alloc, rows, rb.c1[j], tmp, C, -(d * (k - 1) / 2), d, mask);
+    a.pro = PRO_SNAKE; a.pro_alpha = rb.a1[j];
+    JV_TRY(conv_gemm(a, 1, st));
+    const bool last = j == 2;
+    a = conv_args(tmp, C, alloc, rows, rb.c2[j], last ? dst : r, C, -((k - 1) / 2), 1, mask);
+    a.pro = PRO_SNAKE; a.pro_alpha = rb.a2[j];
+    a.res1 = in; a.ldr1 = C;
+    if (last) {
+      a.res2 = extra_res; a.ldr2 = C;
+      a.out_scale = scale;
+      a.accumulate = accumulate;
+    }
+    JV_TRY(conv_gemm(a, 1, st));
+    in = r;
+  }
+  return JV_OK;
+}
+
+}  // namespace
+
+int hift_f0(Context& c, const float* mel, const int* lens, int B, int T, float* f0, hipStream_t st) {
+  JV_TRY(check(c, B, T));
+  HiftWs& w = *c.hws;
+  const HGeo g = make_geo(c, B, T);
+  JV_TRY(prepare_masks(c, g, lens, st));
+  JV_TRY(mel_to_rows(c, g, mel, st));
+  const float* in = w.mel;
+  int lda = 96;
+  float* bufs[2] = {w.f0a, w.f0b};
+  for (int i = 0; i < 5; ++i) {
+    ConvGemmArgs a = conv_args(in, lda, g.alloc[0], g.rows[0], c.hift.f0_conv[i], bufs[i & 1], 512, -1, 1, w.mask[0]);
+    a.act = ACT_ELU;
+    JV_TRY(conv_gemm(a, 1, st));
+    in = bufs[i & 1];
+    lda = 512;
+  }
+  return f0_head(in, c.hift.f0_cls_w, c.hift.f0_cls_b, f0, B, T, H_G0, g.S0, st);
+}
+
+int hift_source(Context& c, const float* f0, const float* phase, const float* noise, int B, int T, float* s, hipStream_t st) {
+  JV_TRY(check(c, B, T));
+  return sine_source(f0, phase, noise, c.hift.src_lin_w, c.hift.src_lin_b, c.hws->frac, s, B, T, st);
+}
+
+int hift_decode(Context& c, const float* mel, const float* s, const int* lens, int B, int T, float* wav, hipStream_t st) {
+  JV_TRY(check(c, B, T));
+  HiftWs& w = *c.hws;
+  const HiftW& h = c.hift;
+  const HGeo g = make_geo(c, B, T);
+  JV_TRY(prepare_masks(c, g, lens, st));
+  JV_TRY(mel_to_rows(c, g, mel, st));
+  float* stft = w.stft_alloc + 16 * 32;
+  JV_TRY(stft_rows(s, stft, w.lens, B, T, g.G[3], g.S[3], g.alloc[3], st));
+
+  // conv_pre (k7, pad 3)
+  {
+    ConvGemmArgs a = conv_args(w.mel, 96, g.alloc[0], g.rows[0], h.conv_pre, w.x0, 512, -3, 1, w.mask[0]);
+    JV_TRY(conv_gemm(a, 1, st));
+  }
+  const float* prev = w.x0;
+  int prevC = 512;
+  const int sd_stride[3] = {15, 3, 1}, sd_off[3] = {-8, -2, 0};
+  for (int i = 0; i < 3; ++i) {
+    const int l = i + 1, C = HIFT_CH >> l;
+    // leaky_relu(0.1) -> ConvTranspose1d as a 3-tap polyphase GEMM: input row r -> output rows UPS*r .. UPS*r+UPS-1
+    {
+      ConvGemmArgs a = conv_args(prev, prevC, g.alloc[i], g.rows[i], h.ups[i], w.x[i], UPS[i] * C, -1, 1, w.mask[i]);
+      a.pro = PRO_LRELU; a.pro_slope = 0.1f;
+      JV_TRY(conv_gemm(a, 1, st));
+      if (i == 2) JV_TRY(reflect_fix(w.x[i], B, g.G[3], g.S[3], C, st));
+    }
+    // source branch: strided conv of the STFT rows, then a ResBlock whose last layer also adds the up-sampled trunk
+    {
+      ConvGemmArgs a = conv_args(stft + sd_off[i] * 32, sd_stride[i] * 32, g.rows[l], g.rows[l], h.src_down[i], w.si[i], C,
+                                 0, 1, nullptr);
+      JV_TRY(conv_gemm(a, 1, st));
+      JV_TRY(resblock(h.src_rb[i], C, g.rows[l], g.alloc[l], w.mask[l], w.si[i], w.r[i], w.tmp[i], w.xs[i], w.x[i], 1.f, 0, st));
+    }
+    // x = xs now holds x_up + si ; MRF: mean of the three ResBlocks, accumulated into w.x[i]
+    for (int j = 0; j < 3; ++j)
+      JV_TRY(resblock(h.rb[3 * i + j], C, g.rows[l], g.alloc[l], w.mask[l], w.xs[i], w.r[i], w.tmp[i], w.x[i], nullptr,
+                      1.f / 3.f, j > 0 ? 1 : 0, st));
+    prev = w.x[i];
+    prevC = C;
+  }
+  // leaky_relu (default slope 0.01) -> conv_post (k7) -> exp / sin -> iSTFT -> clamp
+  {
+    ConvGemmArgs a = conv_args(prev, 64, g.alloc[3], g.rows[3], h.conv_post, w.post, 32, -3, 1, w.mask[3]);
+    a.pro = PRO_LRELU; a.pro_slope = 0.01f;
+    JV_TRY(conv_gemm(a, 1, st));
+  }
+  return istft_head(w.post, w.frames, wav, w.lens, B, T, g.G[3], g.S[3], g.rows[3], st);
+}
+
+}  // namespace jv
+
+
 extern "C" {
-int jv_hift_f0(jv_context*, const float*, const int32_t*, int, int, float*, void*) { return jv::fail(JV_ERR_STATE, "hift not built yet"); }
-int jv_hift_source(jv_context*, const float*, const float*, const float*, int, int, float*, void*) { return jv::fail(JV_ERR_STATE, "hift not built yet"); }
-int jv_hift_decode(jv_context*, const float*, const float*, const int32_t*, int, int, float*, void*) { return jv::fail(JV_ERR_STATE, "hift not built yet"); }
+
+int jv_hift_f0(jv_context* ctx, const float* mel, const int32_t* lens, int B, int T, float* f0, void* stream) {
+  if (!ctx || !mel || !f0) return jv::fail(JV_ERR_ARG, "jv_hift_f0: null argument");
+  JV_HIP(hipSetDevice(ctx->c.device));
+  return jv::hift_f0(ctx->c, mel, lens, B, T, f0, static_cast<hipStream_t>(stream));
 }
+
+int jv_hift_source(jv_context* ctx, const float* f0, const float* phase, const float* noise, int B, int T, float* s,
+                   void* stream) {
+  if (!ctx || !f0 || !phase || !noise || !s) return jv::fail(JV_ERR_ARG, "jv_hift_source: null argument");
+  JV_HIP(hipSetDevice(ctx->c.device));
+  return jv::hift_source(ctx->c, f0, phase, noise, B, T, s, static_cast<hipStream_t>(stream));
+}
+
+int jv_hift_decode(jv_context* ctx, const float* mel, const float* s, const int32_t* lens, int B, int T, float* wav,
+                   void* stream) {
+  if (!ctx || !mel || !s || !wav) return jv::fail(JV_ERR_ARG, "jv_hift_decode: null argument");
+  JV_HIP(hipSetDevice(ctx->c.device));
+  return jv::hift_decode(ctx->c, mel, s, lens, B, T, wav, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

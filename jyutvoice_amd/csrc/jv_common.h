@@ -106,7 +106,8 @@ struct AttnArgs {
 int attention64(const AttnArgs& a, hipStream_t st);
 
 // ---- row-wise / elementwise kernels (rowops.hip) -------------------------------------------------
+// out = LayerNorm_C(x (+ add)) * g + b, optional ReLU, rows with rowmask_out == 0 written as zero
 int layernorm_rows(const float* x, const float* add, float* out, const float* g, const float* b, float eps, long rows,
-                   int C, const unsigned char* rowmask_out, hipStream_t st);
+                   int C, const unsigned char* rowmask_out, hipStream_t st, int relu = 0);
 
 }  // namespace jv

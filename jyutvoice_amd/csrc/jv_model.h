@@ -120,3 +120,8 @@ int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spk
               int n_timesteps, float temperature, const float* t_span_host, float* mel, hipStream_t st);
 
 }  // namespace jv
+
+// the opaque handle of include/jyutvoice_hip.h
+struct jv_context {
+  jv::Context c;
+};

@@ -15,7 +15,7 @@ template <int VPL>   // f32x4 per lane
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                              float* __restrict__ out, const float* __restrict__ g,
                                                              const float* __restrict__ b, float eps, long rows, int C,
-                                                             const unsigned char* __restrict__ rowmask_out) {
+                                                             const unsigned char* __restrict__ rowmask_out, int relu) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
       const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * c4);
       const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 4 * c4);
       f32x4 r = (v[i] - mean) * rstd * gg + bb;
+      if (relu) r = f32x4{fmaxf(r[0], 0.f), fmaxf(r[1], 0.f), fmaxf(r[2], 0.f), fmaxf(r[3], 0.f)};
       if (!keep) r = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(out + row * C + 4 * c4) = r;
     }
@@ -63,16 +64,16 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
 }
 
 int layernorm_rows(const float* x, const float* add, float* out, const float* g, const float* b, float eps, long rows,
-                   int C, const unsigned char* rowmask_out, hipStream_t st) {
+                   int C, const unsigned char* rowmask_out, hipStream_t st, int relu) {
   if (rows <= 0) return JV_OK;
   if (C & 3 || C > 1024) return fail(JV_ERR_ARG, "layernorm_rows: C must be a multiple of 4, <= 1024");
   const dim3 grid((unsigned)cdivl(rows, 4));
   if (C <= 256)
-    hipLaunchKernelGGL((layernorm_rows_kernel<1>), grid, dim3(256), 0, st, x, add, out, g, b, eps, rows, C, rowmask_out);
+    hipLaunchKernelGGL((layernorm_rows_kernel<1>), grid, dim3(256), 0, st, x, add, out, g, b, eps, rows, C, rowmask_out, relu);
   else if (C <= 768)
-    hipLaunchKernelGGL((layernorm_rows_kernel<3>), grid, dim3(256), 0, st, x, add, out, g, b, eps, rows, C, rowmask_out);
+    hipLaunchKernelGGL((layernorm_rows_kernel<3>), grid, dim3(256), 0, st, x, add, out, g, b, eps, rows, C, rowmask_out, relu);
   else
-    hipLaunchKernelGGL((layernorm_rows_kernel<4>), grid, dim3(256), 0, st, x, add, out, g, b, eps, rows, C, rowmask_out);
+    hipLaunchKernelGGL((layernorm_rows_kernel<4>), grid, dim3(256), 0, st, x, add, out, g, b, eps, rows, C, rowmask_out, relu);
   JV_HIP(hipGetLastError());
   return JV_OK;
 }

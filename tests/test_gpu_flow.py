@@ -78,7 +78,8 @@ def test_cfm_batched_equals_singles(eng, tts_sd, noise):
         L = int(lens[b])
         one = oflow.cfm_solve(tts_sd, noise, mu[b:b + 1, :, :L], torch.ones(1, 1, L), spks[b:b + 1], cond[b:b + 1, :, :L], 6)
         assert md(mel[b:b + 1, :, :L], one) <= 3e-4, b
-        assert float(mel[b, :, L:].abs().max()) == 0.0
+        if L < T:
+            assert float(mel[b, :, L:].abs().max()) == 0.0
     # and the single-utterance HIP path agrees with its own batched path bit-for-bit on valid frames
     solo = eng.cfm_solve(mu[1:2, :, :61], None, spks[1:2], cond[1:2, :, :61], 6, 1.0).cpu()
     assert md(solo, mel[1:2, :, :61]) <= 1e-5

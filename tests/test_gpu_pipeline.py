@@ -1,0 +1,170 @@
+"""GPU: text encoder, length regulation, HiFT vocoder and the end-to-end synthesise() path (HIP through the
+C ABI and the mirror classes) against the golden fixtures and the CPU oracle.
+Tolerances (BASELINE.json north_star): mel <= 1e-3 max-abs, waveform <= 1e-4 RMS with the source signal injected."""
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def md(a, b):
+    return float((a.float().cpu() - b.float().cpu()).abs().max())
+
+
+def rms(a, b):
+    return float((a.float().cpu() - b.float().cpu()).pow(2).mean().sqrt())
+
+
+@pytest.fixture(scope="module")
+def models(tts_sd, hift_sd):
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
+    import jyutvoice_amd
+    tts, hift = jyutvoice_amd.build_default("cuda:0")
+    tts.load_state_dict(tts_sd)
+    hift.load_state_dict(hift_sd)
+    return tts, hift
+
+
+@pytest.fixture(scope="module")
+def eng(models):
+    from jyutvoice_amd.runtime import get_runtime
+    return get_runtime("cuda:0").ensure(4, 512, 128)
+
+
+def test_encoder_golden(eng):
+    g = load_golden("G1_encoder")
+    h, mu_x, logw, c = eng.encoder(g["x_ids"], g["x_lengths"], g["lang"], g["tone"], g["word_pos"], g["syllable_pos"],
+                                   g["spk_embed"])
+    assert md(h, g["x"]) <= 2e-4
+    assert md(mu_x, g["mu_x"]) <= 2e-4
+    assert md(logw, g["logw"]) <= 2e-4
+    assert float(h[1, :, 41:].abs().max()) == 0.0 and float(mu_x[1, :, 41:].abs().max()) == 0.0
+
+
+def test_speaker_projection(eng, tts_sd):
+    import torch.nn.functional as F
+    g = load_golden("G1_encoder")
+    _, _, _, c = eng.encoder(g["x_ids"], g["x_lengths"], g["lang"], g["tone"], g["word_pos"], g["syllable_pos"], g["spk_embed"])
+    want = F.linear(F.normalize(g["spk_embed"], dim=1), tts_sd["spk_embed_affine_layer.weight"],
+                    tts_sd["spk_embed_affine_layer.bias"])
+    assert md(c, want) <= 1e-5
+
+
+def test_length_regulation_golden(eng):
+    g = load_golden("G2_length")
+    xl = g["x_mask"].sum(dim=(1, 2)).long()
+    for ls, tag in ((1.0, "ls10"), (0.9, "ls09")):
+        w_ceil, yl, attn, mu_y = eng.length_regulate(g["logw"].cuda(), xl, g["mu_x"].cuda(), ls)
+        assert torch.equal(yl.cpu(), g[f"y_lengths_{tag}"])
+        assert md(w_ceil, g[f"w_ceil_{tag}"]) == 0.0
+        assert torch.equal(attn.cpu().to(torch.uint8), g[f"attn_{tag}"].squeeze(1))
+        assert md(mu_y, g[f"mu_y_{tag}"]) == 0.0        # a gather: bit-exact
+
+
+def test_hift_f0_golden(eng):
+    g = load_golden("G5_hift")
+    f0 = eng.hift_f0(g["mel"])
+    assert md(f0, g["f0"]) <= 2e-3 and md(f0, g["f0"]) / float(g["f0"].abs().max()) <= 2e-5
+
+
+def test_hift_source(eng, hift_sd):
+    from oracle import hift as ohift
+    g = load_golden("G5_hift")
+    noise = g["noise"].float()
+    s = eng.hift_source(g["f0"], g["phase"].squeeze(-1), noise)
+    want = ohift.source(ohift.fold_weight_norm(hift_sd), g["f0"], g["phase"], noise)
+    assert md(s, want) <= 2e-5                 # same sequential fp32 phase accumulation as torch.cumsum
+    assert md(s, g["s"]) <= 2e-4               # fixture keeps the noise draw in fp16
+
+
+def test_hift_decode_golden(eng):
+    g = load_golden("G5_hift")
+    wav = eng.hift_decode(g["mel"], g["s"])
+    assert wav.shape == (2, 480 * 16)
+    assert rms(wav, g["wav"]) <= 1e-4          # north-star tolerance
+    assert rms(wav, g["wav"]) <= 2e-5 and md(wav, g["wav"]) <= 5e-4
+    assert float(wav.abs().max()) <= 0.99 + 1e-6
+
+
+def test_hift_ragged_batch_equals_singles(eng, hift_sd):
+    from oracle import hift as ohift
+    g = torch.Generator().manual_seed(77)
+    T, lens = 24, [24, 13]
+    mel = torch.randn(2, 80, T, generator=g) * 1.5
+    s = torch.tanh(torch.randn(2, 1, 480 * T, generator=g) * 0.3)
+    wav = eng.hift_decode(mel, s, torch.tensor(lens)).cpu()
+    w = ohift.fold_weight_norm(hift_sd)
+    for b, L in enumerate(lens):
+        want = ohift.decode(w, mel[b:b + 1, :, :L], s[b:b + 1, :, :480 * L])
+        assert rms(wav[b:b + 1, :480 * L], want) <= 2e-5, b
+        if L < T:
+            assert float(wav[b, 480 * L:].abs().max()) == 0.0
+
+
+def test_synthesise_golden(models):
+    from jyutvoice_amd import synth
+    tts, _ = models
+    g = load_golden("G9_synthesise")
+    one = synth.batch(1, int(g["n_tokens"]))
+    res = tts.synthesise(one["x"], one["x_lengths"], one["lang"], one["tone"], one["word_pos"], one["syllable_pos"],
+                         one["spk_embed"], None)
+    assert set(res) == {"encoder_outputs", "decoder_outputs", "attn", "mel", "mel_lengths", "rtf"}
+    assert torch.equal(res["mel_lengths"].cpu(), g["mel_lengths"])
+    assert res["attn"].shape == (1, 1, 33, 78) and torch.equal(res["attn"][0, 0].cpu().to(torch.uint8), g["attn"][0])
+    assert md(res["encoder_outputs"], g["encoder_outputs"]) <= 2e-4
+    assert md(res["mel"], g["mel"]) <= 1e-3      # north-star tolerance
+    assert md(res["mel"], g["mel"]) <= 3e-4
+    assert isinstance(res["rtf"], float) and res["rtf"] > 0
+
+
+def test_synthesise_batched_extension(models, tts_sd, noise):
+    from jyutvoice_amd import synth
+    from oracle import tts as otts
+    tts, _ = models
+    b = synth.batch(3, 21, first_index=40, lengths=[21, 15, 9])
+    args = (b["x"], b["x_lengths"], b["lang"], b["tone"], b["word_pos"], b["syllable_pos"], b["spk_embed"], None)
+    with pytest.raises(ValueError, match="requires batch_size=1"):
+        tts.synthesise(*args)
+    res = tts.synthesise(*args, n_timesteps=4, batched=True)
+    for i in range(3):
+        L = int(b["x_lengths"][i])
+        one = otts.synthesise(tts_sd, noise, b["x"][i:i + 1, :L], b["x_lengths"][i:i + 1], b["lang"][i:i + 1, :L],
+                              b["tone"][i:i + 1, :L], b["word_pos"][i:i + 1, :L], b["syllable_pos"][i:i + 1, :L],
+                              b["spk_embed"][i:i + 1], None, n_timesteps=4)
+        ty = int(one["mel_lengths"][0])
+        assert int(res["mel_lengths"][i]) == ty
+        assert md(res["mel"][i:i + 1, :, :ty], one["mel"]) <= 5e-4, i
+
+
+def test_full_chain_shapes(models):
+    from jyutvoice_amd import synth
+    tts, hift = models
+    one = synth.batch(1, 17, first_index=3)
+    res = tts.synthesise(one["x"], one["x_lengths"], one["lang"], one["tone"], one["word_pos"], one["syllable_pos"],
+                         one["spk_embed"], None, n_timesteps=3, length_scale=0.9)
+    hift.manual_seed(0)
+    wav, s = hift.inference(res["mel"])
+    T = res["mel"].shape[2]
+    assert wav.shape == (1, 480 * T) and s.shape == (1, 1, 480 * T)
+    assert torch.isfinite(wav).all() and float(wav.abs().max()) <= 0.99 + 1e-6
+    # cache_source continuation overrides the head of the source signal (generator.py:462-465)
+    wav2, s2 = hift.inference(res["mel"], cache_source=s[:, :, :960].clone())
+    assert torch.equal(s2[:, :, :960], s[:, :, :960])
+
+
+def test_load_errors(tts_sd):
+    import jyutvoice_amd
+    tts, _ = jyutvoice_amd.build_default("cuda:0")
+    bad = dict(tts_sd)
+    bad.pop("dp.proj.bias")
+    with pytest.raises(RuntimeError, match="Missing key"):
+        tts.load_state_dict(bad)
+    bad = dict(tts_sd)
+    bad["dp.proj.bias"] = torch.zeros(2)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        tts.load_state_dict(bad)
+    with pytest.raises(FileNotFoundError):
+        tts.load_pretrain("/nonexistent/pretrain.pt")
