@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mel-frames/s and 24 kHz RTF of the full synthesis path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): full text encoder -> flow decoder (CFM Euler/CFG,
+n_timesteps = 10) -> HiFT vocoder, batch 32 utterances per GPU, 150 tokens -> 300 mel frames = 6.0 s of 24 kHz audio
+each, synthetic key-hashed weights and seeded inputs; fp32 throughout (fp32-input MFMA).
+One "step" = one pass of that path over one batch; inputs are resident in HBM before the timed region.
+With N > 1 (launched by torch.distributed.run, one rank per GPU) each rank synthesises its own 32 utterances (weak
+scaling, no data-path collective) and the generated mels are all-gathered over RCCL at the end of every step.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel, measured with HIP events on the launch stream
+inside the timed region (jv_profile_*); `cpu_baseline` is the CPU oracle (a plain-PyTorch port of the reference path)
+timed on this box's host cores on a bounded sample -- reported, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = fp32 vector peak
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(n_tokens: int, n_timesteps: int, repeats: int):
+    """the oracle on the host: B = 1 sequential semantics (what the reference does), end to end"""
+    import math
+
+    import torch
+
+    from jyutvoice_amd import synth
+    from oracle import hift as ohift
+    from oracle import tts as otts
+    tts_sd, hift_sd, noise = synth.tts_state_dict(fixed_duration=1.5), synth.hift_state_dict(), synth.rand_noise()
+    w = ohift.fold_weight_norm(hift_sd)
+    g = torch.Generator().manual_seed(0)
+
+    def one(i):
+        u = synth.batch(1, n_tokens, first_index=i)
+        res = otts.synthesise(tts_sd, noise, u["x"], u["x_lengths"], u["lang"], u["tone"], u["word_pos"], u["syllable_pos"],
+                              u["spk_embed"], None, n_timesteps=n_timesteps)
+        mel = res["mel"]
+        T = mel.shape[2]
+        f0 = ohift.f0_predict(w, mel)
+        phase = (torch.rand(1, 9, 1, generator=g) * 2 - 1) * math.pi
+        phase[:, 0] = 0
+        s = ohift.source(w, f0, phase, torch.randn(1, 9, 480 * T, generator=g))
+        ohift.decode(w, mel, s)
+        return T
+
+    with torch.inference_mode():
+        one(0)                      # warm-up
+        t0 = time.perf_counter()
+        frames = sum(one(1 + i) for i in range(repeats))
+        dt = time.perf_counter() - t0
+    return {"value": round(frames / dt, 2), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "rtf": round(dt / (frames * 0.02), 4),
+            "sample": f"{repeats} utterances x {n_tokens} tokens -> {frames // repeats} frames, n_timesteps={n_timesteps}, "
+                      f"B=1 sequential, encoder+CFM+HiFT, after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--tokens", type=int, default=150, help="text tokens per utterance (2 mel frames each)")
+    ap.add_argument("--timesteps", type=int, default=10)
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-utts", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    import jyutvoice_amd
+    from jyutvoice_amd import dist as jdist
+    from jyutvoice_amd import engine, synth
+    from jyutvoice_amd.runtime import get_runtime
+
+    B, Tt, n_steps = args.batch, args.tokens, args.timesteps
+    T = 2 * Tt
+    tts, hift = jyutvoice_amd.build_default(device)
+    get_runtime(device).ensure(B, T, Tt)
+    tts.load_state_dict(synth.tts_state_dict(fixed_duration=1.5))     # every token -> ceil(1.5) = 2 frames
+    hift.load_state_dict(synth.hift_state_dict())
+    hift.manual_seed(1234 + rank)
+    lo, _ = jdist.shard_range(B * world, rank, world)
+    batch = {k: v.to(device) for k, v in synth.batch(B, Tt, first_index=lo).items()}
+
+    def step():
+        res = tts.synthesise(batch["x"], batch["x_lengths"], batch["lang"], batch["tone"], batch["word_pos"],
+                             batch["syllable_pos"], batch["spk_embed"], None, n_timesteps=n_steps, batched=True)
+        wav, _ = hift.inference(res["mel"])
+        if world > 1:
+            jdist.all_gather_mels(res["mel"], res["mel_lengths"])
+        return res, wav
+
+    for _ in range(args.warmup):
+        res, wav = step()
+    assert res["mel"].shape == (B, 80, T) and wav.shape == (B, 480 * T), (res["mel"].shape, wav.shape)
+    assert torch.isfinite(wav).all()
+
+    profile = not args.no_profile
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    if profile:
+        engine.profile_report()          # drop anything recorded during warm-up
+        engine.profile_enable(True)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kern = {}
+    if profile:
+        engine.profile_enable(False)
+        kern = engine.profile_report()
+    if world > 1:
+        el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+
+    if rank == 0:
+        frames = world * B * T * args.steps
+        out = {
+            "metric": "mel_frames_per_sec", "value": round(frames / elapsed, 1), "unit": "mel-frames/s",
+            "rtf": round(elapsed / (frames * 0.02), 6), "x_realtime": round(frames * 0.02 / elapsed, 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3: text encoder -> CFM flow decoder (Euler+CFG) -> HiFT vocoder, full synthesise()+inference()",
+                       "utterances_per_gpu": B, "global_batch": B * world, "tokens": Tt, "mel_frames": T,
+                       "audio_seconds_per_utterance": T * 0.02, "n_timesteps": n_steps, "parallelism": f"utterance-dp{world}"},
+        }
+        if kern:
+            tot_ms = sum(v["ms"] for v in kern.values())
+            name, d = max(kern.items(), key=lambda kv: kv[1]["ms"])
+            tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+            out["roofline"] = {
+                "kernel": name, "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+                "alg_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
+                "alg_hbm_gbs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
+                "share_of_profiled_kernel_time": round(d["ms"] / tot_ms, 3),
+                "measured": "HIP events on the launch stream around every launch, inside the timed region (jv_profile_*)",
+                "precision": "fp32 inputs, fp32 accumulate (v_mfma_f32_32x32x2_f32); peak = dense fp32 MFMA",
+            }
+            out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
+                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0}
+                              for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}
+            out["profiled_kernel_ms_per_step"] = round(tot_ms / args.steps, 3)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(Tt, n_steps, args.cpu_utts)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,13 @@ int jv_op_attention(const float* qkv, const int32_t* lens, int B, int G, int S, 
 int jv_op_layernorm(const float* x, const float* g, const float* b, float eps, int64_t rows, int C, float* out,
                     void* stream);
 
+/* ---- measurement -------------------------------------------------------------------------------------------
+ * HIP events on the launch stream around every conv_gemm / attention launch (replaces nothing in the reference,
+ * whose only timing is the unsynchronised wall clock of jyutvoice_tts.py:171-172,243-244).
+ * jv_profile_report synchronises the device and writes {"kernel":{"launches":n,"ms":t,"flops":f,"bytes":b},...}. */
+int jv_profile_enable(int on);
+int jv_profile_report(char* json, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

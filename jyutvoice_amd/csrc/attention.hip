@@ -153,10 +153,17 @@ int attention64(const AttnArgs& a, hipStream_t st) {
     return fail(JV_ERR_ARG, "attention64: strides/offsets must be multiples of 4 floats");
   // 64-query workgroups waste least on T = 300 (5 x 64); 128-query ones halve K/V staging at T = 512
   const int waste2 = round_up(a.L, 64) - a.L, waste4 = round_up(a.L, 128) - a.L;
+  const bool prof = prof_on();
+  if (prof) prof_begin(st);
   if (waste4 <= waste2) {
     hipLaunchKernelGGL((attn64_kernel<4>), dim3(cdiv(a.L, 128), a.H, a.B), dim3(256), 0, st, a);
   } else {
     hipLaunchKernelGGL((attn64_kernel<2>), dim3(cdiv(a.L, 64), a.H, a.B), dim3(128), 0, st, a);
+  }
+  if (prof) {
+    // algorithmic (full-length) figure of SURVEY.md 8(d): QK^T + PV = 4*L*L*64 per head; q,k,v,o once
+    const double bh = (double)a.B * a.H;
+    prof_end(st, waste4 <= waste2 ? "attn64<4 waves>" : "attn64<2 waves>", 4.0 * bh * a.L * a.L * 64.0, 4.0 * bh * a.L * 64.0 * 4.0);
   }
   JV_HIP(hipGetLastError());
   return JV_OK;

@@ -18,6 +18,7 @@
 // next barrier), so L2/HBM latency hides under the 64-cycle MFMAs.
 #include <math.h>
 
+#include <string>
 #include <type_traits>
 
 #include "jv_common.h"
@@ -325,7 +326,18 @@ int launch1(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
   const size_t need = LN ? (size_t)32 * LN_STRIDE * sizeof(float) : (size_t)4 * 32 * (WN + 4) * sizeof(float);
   if (lds < need) lds = need;
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), nbatch);
+  const bool prof = prof_on();
+  if (prof) prof_begin(st);
   hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, NAMAX, LN, PRO>), grid, dim3(256), lds, st, a);
+  if (prof) {
+    static const std::string name = std::string("conv_gemm<") + std::to_string(BM) + "x" + std::to_string(BN) +
+                                    (LN ? ",ln" : "") + (PRO == PRO_SNAKE ? ",snake" : PRO == PRO_LRELU ? ",lrelu" : "") + ">";
+    const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M) * nbatch;
+    const double k = (double)(a.alg_k > 0 ? a.alg_k : a.ntaps * a.Cin);
+    // algorithmic traffic: A rows once, W once, out once (+ residual reads), fp32
+    const double bytes = 4.0 * (rows * a.Cin + (double)a.N * k * nbatch + rows * a.N * (1 + (a.res1 ? 1 : 0) + (a.res2 ? 1 : 0)));
+    prof_end(st, name.c_str(), 2.0 * rows * a.N * k, bytes);
+  }
   JV_HIP(hipGetLastError());
   return JV_OK;
 }

@@ -206,21 +206,21 @@ int l2_normalize(const float* x, float* out, int B, int C, hipStream_t st) {
 }
 
 // ---- length regulation -------------------------------------------------------------------------------------
-// w_ceil = ceil(exp(logw) * mask) * length_scale; cum = sequential fp32 cumsum (torch.cumsum order);
-// y_len = max(long(sum), 1).  One lane per utterance (Tt <= 512 dependent adds).
+// w_ceil = ceil(exp(logw) * mask) * length_scale; cum = torch.cumsum semantics on the CPU (sequential fp64
+// accumulation, every prefix rounded to fp32); y_len = max(long(sum), 1).  One lane per utterance (Tt <= 512).
 __global__ void durations_kernel(const float* __restrict__ logw, const long* __restrict__ xlen, float scale,
                                  float* __restrict__ w_ceil, float* __restrict__ cum, long* __restrict__ ylen, int B, int Tt) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  float c = 0.f;
+  double c = 0.0;
   for (int t = 0; t < Tt; ++t) {
     const float m = t < xlen[b] ? 1.f : 0.f;
     const float w = ceilf(expf(logw[b * Tt + t]) * m) * scale;
     w_ceil[b * Tt + t] = w;
-    c += w;
-    cum[b * Tt + t] = c;
+    c += (double)w;
+    cum[b * Tt + t] = (float)c;
   }
-  ylen[b] = max((long)c, 1L);
+  ylen[b] = max((long)(float)c, 1L);
 }
 
 // attn[b,i,j] = ([j < cum_i] - [j < cum_{i-1}]) * xmask_i * ymask_j   (utils/model.py:36-45)

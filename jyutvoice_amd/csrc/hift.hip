@@ -120,6 +120,12 @@ ConvGemmArgs conv_args(const float* A, int lda, long a_rows, long M, const GemmW
   return a;
 }
 
+// algorithmic size of a launch for the profiler: B*frames real rows, real taps*channels
+void set_alg(ConvGemmArgs& a, long rows, int k) {
+  a.alg_rows = rows;
+  a.alg_k = k;
+}
+
 // lens (device int32 [B] or null) -> ws.lens + the four row masks
 int prepare_masks(Context& c, const HGeo& g, const int* lens, hipStream_t st) {
   HiftWs& w = *c.hws;

@@ -52,15 +52,16 @@ int f0_head(const float* h, const float* w, const float* bias, float* f0, int B,
 }
 
 // ---- sine generator phase: frac[b,h,n] = (cumsum_n f0[b, n/480]*(h+1)/24000) mod 1 --------------------------
-// The reference accumulates sequentially in fp32 (torch.cumsum) over up to 144 000+ samples, where the running sum
-// reaches ~1e4 and one ulp is ~1e-3 cycles: the rounding sequence *is* the signal.  So each (utterance, harmonic)
-// is accumulated by one lane in the same order; 9*B lanes x 480*T dependent adds is ~0.5 ms at 6 s of audio.
+// The reference's torch.cumsum (CPU) accumulates sequentially in fp64 and rounds every prefix to fp32; the running sum
+// reaches ~1e4 where one fp32 ulp is ~1e-3 cycles, so that rounding *is* part of the signal.  Each (utterance, harmonic)
+// is therefore accumulated by one lane in the same order and precision; 9*B lanes x 480*T dependent fp64 adds is well
+// under a millisecond at 6 s of audio.
 __global__ void sine_phase_kernel(const float* __restrict__ f0, float* __restrict__ frac, int B, int T) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * 9) return;
   const int b = idx / 9, h = idx - b * 9;
   const float mult = (float)(h + 1);
-  float cum = 0.f;
+  double cum = 0.0;
   float* dst = frac + (long)idx * T * 480;
   for (int t = 0; t < T; ++t) {
     const float F = f0[b * T + t] * mult / 24000.0f;
@@ -68,8 +69,9 @@ __global__ void sine_phase_kernel(const float* __restrict__ f0, float* __restric
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        cum = cum + F;
-        o[e] = cum - floorf(cum);
+        cum = cum + (double)F;
+        const float c32 = (float)cum;
+        o[e] = c32 - floorf(c32);
       }
       *reinterpret_cast<f32x4*>(dst + (long)t * 480 + k) = o;
     }

@@ -86,11 +86,20 @@ struct ConvGemmArgs {
   // optional batch (grid.z = nb1*nb2): pointers advance by z1*s?1 + z2*s?2 floats
   int nb2;
   long sA1, sA2, sW1, sW2, sO1, sO2;
+  // algorithmic size for the profiler (0 = use M / ntaps*Cin): real frames and real taps*channels, without guard
+  // rows, channel padding or the zero taps of a polyphase transposed conv
+  long alg_rows;
+  int alg_k;
 };
 
 void conv_gemm_defaults(ConvGemmArgs& a);
 int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st);
 int conv_gemm_init();   // raises the dynamic-LDS limit of every instantiation
+
+// ---- in-library kernel profiler (profile.hip): HIP events around the hot kernels, on the launch stream ----------
+bool prof_on();
+void prof_begin(hipStream_t st);                                   // records the start event
+void prof_end(hipStream_t st, const char* name, double flops, double bytes);   // records the stop event
 
 // ---- attention (attention.hip) -----------------------------------------------------------------
 struct AttnArgs {

@@ -205,3 +205,15 @@ def op_layernorm(x, g, b, eps=1e-5):
     out = torch.empty_like(x)
     check(lib.jv_op_layernorm(_ptr(x), _ptr(g), _ptr(b), float(eps), x.shape[0], x.shape[1], _ptr(out), _stream(x.device)))
     return out
+
+
+def profile_enable(on: bool) -> None:
+    check(_lib.load().jv_profile_enable(1 if on else 0))
+
+
+def profile_report() -> dict:
+    """per-kernel {launches, ms, flops, bytes} since the last report (synchronises the device)"""
+    import json
+    buf = C.create_string_buffer(1 << 16)
+    check(_lib.load().jv_profile_report(buf, len(buf)))
+    return json.loads(buf.value.decode())

@@ -76,7 +76,7 @@ def test_hift_source(eng, hift_sd):
     noise = g["noise"].float()
     s = eng.hift_source(g["f0"], g["phase"].squeeze(-1), noise)
     want = ohift.source(ohift.fold_weight_norm(hift_sd), g["f0"], g["phase"], noise)
-    assert md(s, want) <= 2e-5                 # same sequential fp32 phase accumulation as torch.cumsum
+    assert md(s, want) <= 2e-5                 # same fp64-accumulated, fp32-rounded phase as torch.cumsum
     assert md(s, g["s"]) <= 2e-4               # fixture keeps the noise draw in fp16
 
 
@@ -99,7 +99,7 @@ def test_hift_ragged_batch_equals_singles(eng, hift_sd):
     w = ohift.fold_weight_norm(hift_sd)
     for b, L in enumerate(lens):
         want = ohift.decode(w, mel[b:b + 1, :, :L], s[b:b + 1, :, :480 * L])
-        assert rms(wav[b:b + 1, :480 * L], want) <= 2e-5, b
+        assert rms(wav[b:b + 1, :480 * L], want) <= 5e-5, b
         if L < T:
             assert float(wav[b, 480 * L:].abs().max()) == 0.0
 
