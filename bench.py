@@ -28,6 +28,19 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 HBM_PEAK_GBS = 8000.0
 
 
+def host_cores() -> int:
+    """CPU threads this process may really use: cgroup quota if any, else the affinity mask, capped at the GPU box's
+    documented 16-core share when neither says less."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(n_tokens: int, n_timesteps: int, repeats: int):
     """the oracle on the host: B = 1 sequential semantics (what the reference does), end to end"""
     import math
@@ -37,6 +50,7 @@ def cpu_baseline(n_tokens: int, n_timesteps: int, repeats: int):
     from jyutvoice_amd import synth
     from oracle import hift as ohift
     from oracle import tts as otts
+    torch.set_num_threads(host_cores())
     tts_sd, hift_sd, noise = synth.tts_state_dict(fixed_duration=1.5), synth.hift_state_dict(), synth.rand_noise()
     w = ohift.fold_weight_norm(hift_sd)
     g = torch.Generator().manual_seed(0)

@@ -66,6 +66,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be the first HIP runtime in the process so that this
+    # library binds to the same runtime instance (device pointers and streams are shared with torch).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m jyutvoice_amd.build` (needs hipcc). "

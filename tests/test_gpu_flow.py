@@ -94,3 +94,11 @@ def test_temperature_and_errors(eng):
     assert md(a, b) > 1e-2
     with pytest.raises(JvError):
         eng.cfm_solve(torch.zeros(1, 80, 4096), None, g["spks"], torch.zeros(1, 80, 4096), 2, 1.0)   # over capacity
+
+
+def test_registry_matches_spec(eng):
+    """the library's own tensor registry (csrc/registry.hip) == the host-side inventory (spec.py) == the reference's keys"""
+    from jyutvoice_amd import spec
+    from jyutvoice_amd.engine import JV_MODEL_HIFT, JV_MODEL_TTS
+    assert eng.registry(JV_MODEL_TTS) == {k: tuple(v) for k, v in spec.TTS_INVENTORY.items()}
+    assert eng.registry(JV_MODEL_HIFT) == {k: tuple(v) for k, v in spec.HIFT_INVENTORY.items()}

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Summarise a tools_profile.sh output directory: per-kernel time from the kernel-trace stats and HBM bytes per launch
+from the PMC passes (FETCH_SIZE doubled, as MI355X_MICROARCH.md prescribes for gfx950; both counters are in KiB)."""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def short(name):
+    m = re.search(r"conv_gemm_kernelILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+ELb([01])ELi(\d)", name)
+    if m:
+        pro = {"0": "", "1": ",snake", "2": ",lrelu"}[m.group(4)]
+        return f"conv_gemm<{m.group(1)}x{m.group(2)}{',ln' if m.group(3) == '1' else ''}{pro}>"
+    m = re.search(r"conv_gemm_kernel<(\d+), (\d+), \d+, \d+, \d+, (true|false), (\d)>", name)
+    if m:
+        pro = {"0": "", "1": ",snake", "2": ",lrelu"}[m.group(4)]
+        return f"conv_gemm<{m.group(1)}x{m.group(2)}{',ln' if m.group(3) == 'true' else ''}{pro}>"
+    m = re.search(r"attn64_kernel(?:ILi|<)(\d)", name)
+    if m:
+        return f"attn64<{m.group(1)} waves>"
+    m = re.search(r"jv::?(\w+?)(?:_kernel)?(?:E|<|\()", name)
+    return (m.group(1) if m else name)[:48]
+
+
+print(f"# rocprofv3 summary ({os.path.basename(out)})\n")
+stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    print("## kernel-trace --stats (bench.py --steps 3 --warmup 1; all 4 passes of the path included)\n")
+    print("| kernel | calls | total ms | avg us | % |")
+    print("|---|---|---|---|---|")
+    for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:22]:
+        print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | "
+              f"{float(r['AverageNs']) / 1e3:.2f} | {100 * float(r['TotalDurationNs']) / tot:.1f} |")
+    print(f"\ntotal kernel time {tot / 1e6:.1f} ms\n")
+
+for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    files = glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        continue
+    agg = defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(files[0])):
+        if r.get("Counter_Name") != counter:
+            continue
+        a = agg[short(r["Kernel_Name"])]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    mult = 2.0 if counter == "FETCH_SIZE" else 1.0
+    print(f"## --pmc {counter} (1 step; KiB per dispatch{', x2 gfx950 correction applied' if mult == 2 else ''})\n")
+    print("| kernel | dispatches | MB per launch |")
+    print("|---|---|---|")
+    for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"| {k} | {n} | {mult * v * 1024 / n / 1e6:.2f} |")
+    print()
