@@ -129,9 +129,7 @@ def main():
         return res, wav
 
     for _ in range(args.warmup):
-        res, wav = step()
-    assert res["mel"].shape == (B, 80, T) and wav.shape == (B, 480 * T), (res["mel"].shape, wav.shape)
-    assert torch.isfinite(wav).all()
+        step()
 
     profile = not args.no_profile
     torch.cuda.synchronize(device)
@@ -143,11 +141,13 @@ def main():
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        res, wav = step()
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    assert res["mel"].shape == (B, 80, T) and wav.shape == (B, 480 * T), (res["mel"].shape, wav.shape)
+    assert torch.isfinite(wav).all() and torch.isfinite(res["mel"]).all()
     kern = {}
     if profile:
         engine.profile_enable(False)

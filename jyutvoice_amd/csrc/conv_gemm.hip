@@ -18,6 +18,8 @@
 // next barrier), so L2/HBM latency hides under the 64-cycle MFMAs.
 #include <math.h>
 
+#include <stdlib.h>
+
 #include <string>
 #include <type_traits>
 
@@ -403,6 +405,10 @@ int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
     const long tiles = (long)cdiv(a.M, cands[i].bm) * cdiv(a.N, cands[i].bn) * nbatch;
     const double cost = (double)cdivl(tiles, 256) * cands[i].bm * cands[i].bn / cands[i].eff;
     if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+  }
+  if (const char* force = getenv("JV_TILE")) {   // tuning aid: force a tile variant (0, 1, 2)
+    const int f = atoi(force);
+    if (f >= 0 && f <= 2 && !((f == 0 && 128 + span > 192) || (f > 0 && 64 + span > 128))) best = f;
   }
   switch (best) {
     case 0: return launch<128, 128, 64, 64, 6>(a, nbatch, st);
