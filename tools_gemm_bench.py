@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the conv_gemm / attention kernels on the estimator's shapes at C3 (M = 19.3K rows).
+    JV_TILE=0|1|2 python tools_gemm_bench.py      (tuning aid; prints TFLOP/s per shape)"""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from jyutvoice_amd.engine import op_attention, op_conv_gemm  # noqa: E402
+
+dev = torch.device("cuda:0")
+M = 4 + 64 * 304
+g = torch.Generator().manual_seed(0)
+
+
+def timeit(fn, n=20):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e-3
+
+
+shapes = [("qkv   K256 N1536", 256, 1536, 1, None), ("ff1   K256 N1024", 256, 1024, 1, None),
+          ("ff2   K1024 N256", 1024, 256, 1, None), ("out   K512 N256", 512, 256, 1, None),
+          ("res   K256 N256", 256, 256, 1, None), ("conv3 K768 N256", 256, 256, 3, None),
+          ("conv3+LN K768 N256", 256, 256, 3, "ln"), ("conv3+LN K960 N256", 320, 256, 3, "ln")]
+for name, cin, n, taps, ln in shapes:
+    A = torch.randn(M + 64, cin, generator=g).to(dev)
+    W = (torch.randn(n, taps * cin, generator=g) / math.sqrt(taps * cin)).to(dev)
+    b = torch.randn(n, generator=g).to(dev)
+    kw = {}
+    if ln:
+        kw["ln"] = (torch.ones(n, device=dev), torch.zeros(n, device=dev))
+        kw["act"] = "mish"
+    t = timeit(lambda: op_conv_gemm(A, W, b, ntaps=taps, tap_row0=-(taps - 1), M=M, **kw))
+    print(f"{name:22s} {t * 1e6:8.1f} us  {2.0 * M * n * taps * cin / t / 1e12:7.1f} TF")
+for L in (300, 512):
+    B = 64 if L == 300 else 16
+    S = L + 4
+    qkv = torch.randn(4 + B * S + 8, 1536, generator=g).to(dev)
+    lens = torch.full((B,), L, dtype=torch.int32, device=dev)
+    t = timeit(lambda: op_attention(qkv, lens, B, 4, S, L))
+    print(f"attention L={L} B'={B:3d}   {t * 1e6:8.1f} us  {4.0 * B * 8 * L * L * 64 / t / 1e12:7.1f} TF")
