@@ -31,7 +31,10 @@ shapes = [("qkv   K256 N1536", 256, 1536, 1, None), ("ff1   K256 N1024", 256, 10
           ("ff2   K1024 N256", 1024, 256, 1, None), ("out   K512 N256", 512, 256, 1, None),
           ("res   K256 N256", 256, 256, 1, None), ("conv3 K768 N256", 256, 256, 3, None),
           ("conv3+LN K768 N256", 256, 256, 3, "ln"), ("conv3+LN K960 N256", 320, 256, 3, "ln")]
+only = os.environ.get("JV_ONLY")
 for name, cin, n, taps, ln in shapes:
+    if only and not name.startswith(only):
+        continue
     A = torch.randn(M + 64, cin, generator=g).to(dev)
     W = (torch.randn(n, taps * cin, generator=g) / math.sqrt(taps * cin)).to(dev)
     b = torch.randn(n, generator=g).to(dev)
@@ -42,6 +45,8 @@ for name, cin, n, taps, ln in shapes:
     t = timeit(lambda: op_conv_gemm(A, W, b, ntaps=taps, tap_row0=-(taps - 1), M=M, **kw))
     print(f"{name:22s} {t * 1e6:8.1f} us  {2.0 * M * n * taps * cin / t / 1e12:7.1f} TF")
 for L in (300, 512):
+    if only and only != "attn":
+        continue
     B = 64 if L == 300 else 16
     S = L + 4
     qkv = torch.randn(4 + B * S + 8, 1536, generator=g).to(dev)
