@@ -7,23 +7,31 @@
 // "same" / dilated Conv1d (a tap is a row offset in the row buffer), strided Conv1d (lda = stride*C,
 // Cin = k*C) and ConvTranspose1d (polyphase: N = stride*Cout, 3 taps, weights packed per phase).
 //
-// Tiling: 256 threads = 4 waves, each wave owns WM x WN outputs as (WM/32)x(WN/32) MFMA tiles.
+// Tiling: 256 threads = 4 waves (2x2), each wave owns WM x WN outputs as (WM/32)x(WN/32) MFMA tiles.
 // Per K-chunk of 32 channels the A *window* (BM + (ntaps-1)*dil rows) is staged into LDS once --
 // with the prologue (mask select, Snake, LeakyReLU) applied on the way -- and reused by every tap;
 // the weight tile [BN][32] is staged per (tap, chunk).  Rows are 36 floats apart in LDS so the
 // ds_read_b128 operand fetches (16 rows of one k-quad per lane group) are bank-conflict free.
 // K order inside a chunk is permuted (lane half h owns k = 16h..16h+15) so one b128 read feeds four
 // MFMA steps; A and W use the same permutation, so the sum is unchanged.
-// Global->LDS staging is register-prefetched one step ahead (issue before the MFMAs, write after the
-// next barrier), so L2/HBM latency hides under the 64-cycle MFMAs.
+//
+// Pipeline (round-1 PMC: two barriers around the LDS refill left the MFMA pipe 46 % busy): LDS holds TWO A windows and
+// TWO weight tiles.  Step s computes from buffers (c&1, s&1) while, between the two halves of its MFMA stream, the
+// wave writes the registers prefetched during step s-1 into the *other* buffers and issues the global loads for step
+// s+2 -- so the refill runs under queued MFMAs and one barrier per step suffices.
+//
+// Workgroups are numbered so that each XCD (private 4 MiB L2) gets a contiguous run of tiles with n fastest: the
+// N/BN tiles that share an A row-panel run together on one XCD and the panel is fetched from HBM once
+// (round 1: FETCH_SIZE was 2.6x the algorithmic bytes with the default round-robin order).
 #include <math.h>
-
 #include <stdlib.h>
 
 #include <string>
 #include <type_traits>
 
 #include "jv_common.h"
+#include "jv_device.h"
+#include "jv_ops.h"
 
 namespace jv {
 
@@ -31,21 +39,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LDS_STRIDE = 36;
-constexpr int LN_STRIDE = 260;
 
-__device__ __forceinline__ float act_apply(float v, int act) {
-  switch (act) {
-    case ACT_RELU: return fmaxf(v, 0.f);
-    case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-    case ACT_MISH: return v * tanhf(log1pf(expf(v)));
-    case ACT_ELU: return v > 0.f ? v : expm1f(v);
-    case ACT_SILU: return v / (1.f + expf(-v));
-    default: return v;
-  }
-}
-
-template <int BM, int BN, int WM, int WN, int NAMAX, bool LN, int PRO>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p) {
+template <int BM, int BN, int WM, int WN, int NAMAX, int PRO>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int WAVES_N = BN / WN;
@@ -56,7 +52,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p) {
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int r32 = lane & 31, half = lane >> 5;
   const int r8 = tid >> 3, c4 = tid & 7;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+  // XCD-aware tile id: blocks b and b+8 share an XCD; give each XCD a contiguous range, n fastest
+  int m0, n0;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    n0 = (lid % tiles_n) * BN;
+    m0 = (lid / tiles_n) * BM;
+  }
 
   const float* A = p.A;
   const float* W = p.W;
@@ -71,8 +76,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p) {
   const int ntaps = p.ntaps, dil = p.tap_dil;
   const int win = BM + (ntaps - 1) * dil;
   const int na = (win + 31) >> 5;
-  float* ldsA = smem;
-  float* ldsW = smem + win * LDS_STRIDE;
+  float* const ldsA0 = smem;                                   // [2][win][36]
+  float* const ldsW0 = smem + 2 * win * LDS_STRIDE;            // [2][BN][36]
 
   // which of this thread's window rows exist and are unmasked (constant over the K loop)
   unsigned avalid = 0;
@@ -104,7 +109,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p) {
       pw[i] = (n < p.n_rows_w) ? *reinterpret_cast<const f32x4*>(W + (long)n * p.ldw + kb) : zero4;
     }
   };
-  auto store_A = [&](int c0) {
+  auto store_A = [&](int c0, int buf) {
+    float* dst = ldsA0 + buf * win * LDS_STRIDE;
     f32x4 al = {1.f, 1.f, 1.f, 1.f};
     if (PRO == PRO_SNAKE) al = *reinterpret_cast<const f32x4*>(p.pro_alpha + c0 + 4 * c4);
 #pragma unroll
@@ -122,14 +128,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.pro_slope;
         }
-        *reinterpret_cast<f32x4*>(ldsA + r * LDS_STRIDE + 4 * c4) = v;
+        *reinterpret_cast<f32x4*>(dst + r * LDS_STRIDE + 4 * c4) = v;
       }
     }
   };
-  auto store_W = [&]() {
+  auto store_W = [&](int buf) {
+    float* dst = ldsW0 + buf * BN * LDS_STRIDE;
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
-      *reinterpret_cast<f32x4*>(ldsW + (r8 + 32 * i) * LDS_STRIDE + 4 * c4) = pw[i];
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(dst + (r8 + 32 * i) * LDS_STRIDE + 4 * c4) = pw[i];
   };
 
   f32x16 acc[MT][NT];
@@ -140,26 +146,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
 
-  const int nchunks = p.Cin >> 5;
-  const int nsteps = nchunks * ntaps;
-  load_A(0);
-  load_W(0, 0);
-  int c = 0, j = 0;
-  for (int s = 0; s < nsteps; ++s) {
-    __syncthreads();
-    if (j == 0) store_A(c * 32);
-    store_W();
-    __syncthreads();
-    int j2 = j + 1, c2 = c;
-    if (j2 == ntaps) { j2 = 0; c2 = c + 1; }
-    if (s + 1 < nsteps) {
-      if (j2 == 0) load_A(c2 * 32);
-      load_W(j2, c2 * 32);
-    }
-    const float* la = ldsA + (wm * WM + r32 + j * dil) * LDS_STRIDE + 16 * half;
-    const float* lw = ldsW + (wn * WN + r32) * LDS_STRIDE + 16 * half;
+  auto mfma_quads = [&](const float* la, const float* lw, int q_lo) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = q_lo; q < q_lo + 2; ++q) {
       f32x4 a[MT], b[NT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(la + mt * 32 * LDS_STRIDE + 4 * q);
@@ -175,138 +164,104 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p) {
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
         }
     }
-    j = j2;
-    c = c2;
+  };
+
+  // ---- main loop: step s = (chunk c, tap j); registers hold exactly one pending A window and one pending W tile ----
+  const int nchunks = p.Cin >> 5;
+  const int nsteps = nchunks * ntaps;
+  load_A(0);
+  load_W(0, 0);
+  store_A(0, 0);
+  store_W(0);
+  if (nsteps > 1) load_W(ntaps > 1 ? 1 : 0, ntaps > 1 ? 0 : 32);      // W of step 1
+  if (ntaps == 1 && nchunks > 1) load_A(32);                          // A of chunk 1 is stored during step 0
+  __syncthreads();
+
+  int c = 0, j = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    const float* la = ldsA0 + (c & 1) * win * LDS_STRIDE + (wm * WM + r32 + j * dil) * LDS_STRIDE + 16 * half;
+    const float* lw = ldsW0 + (s & 1) * BN * LDS_STRIDE + (wn * WN + r32) * LDS_STRIDE + 16 * half;
+    mfma_quads(la, lw, 0);
+    // refill the other buffers under the queued MFMAs
+    int j1 = j + 1, c1 = c;                      // step s+1
+    if (j1 == ntaps) { j1 = 0; c1 = c + 1; }
+    if (s + 1 < nsteps) {
+      store_W((s + 1) & 1);
+      if (j == ntaps - 1) store_A(c1 * 32, c1 & 1);
+      int j2 = j1 + 1, c2 = c1;                  // step s+2
+      if (j2 == ntaps) { j2 = 0; c2 = c1 + 1; }
+      if (s + 2 < nsteps) load_W(j2, c2 * 32);
+      if (j1 == ntaps - 1 && c1 + 1 < nchunks) load_A((c1 + 1) * 32);   // stored during step s+1
+    }
+    mfma_quads(la, lw, 2);
+    __syncthreads();
+    j = j1;
+    c = c1;
   }
 
-  // ---- epilogue: accumulators -> LDS (32 rows per pass) -> rolled, float4-coalesced finish -----------
-  if constexpr (!LN) {
-    constexpr int ES = WN + 4;                       // per-wave slab [32][WN+4]
-    float* slab = smem + wave * 32 * ES;
-    auto pass = [&](auto mt_tag) {
-      constexpr int mt = decltype(mt_tag)::value;
-      __syncthreads();
+  // ---- epilogue: accumulators -> per-wave LDS slab (32 rows per pass) -> rolled, float4-coalesced finish ----------
+  constexpr int ES = WN + 4;
+  float* slab = smem + wave * 32 * ES;
+  auto pass = [&](auto mt_tag) {
+    constexpr int mt = decltype(mt_tag)::value;
+    if (mt > 0) __syncthreads();
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-          slab[((e & 3) + 8 * (e >> 2) + 4 * half) * ES + nt * 32 + r32] = acc[mt][nt][e];
-      __syncthreads();
-      constexpr int C4 = WN / 4;                     // float4 columns per row
-      constexpr int RPI = 64 / C4;                   // rows per iteration
-      const int col = (lane % C4) * 4, rsub = lane / C4;
-      const int n = n0 + wn * WN + col;
+      for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * half) * ES + nt * 32 + r32] = acc[mt][nt][e];
+    __syncthreads();
+    constexpr int C4 = WN / 4;                     // float4 columns per row
+    constexpr int RPI = 64 / C4;                   // rows per iteration
+    const int col = (lane % C4) * 4, rsub = lane / C4;
+    const int n = n0 + wn * WN + col;
 #pragma unroll 1
-      for (int it = 0; it < 32 / RPI; ++it) {
-        const int row = it * RPI + rsub;
-        const int m = m0 + wm * WM + mt * 32 + row;
-        if (m >= p.M || n >= p.N) continue;
-        const float4 x = *reinterpret_cast<const float4*>(slab + row * ES + col);
-        float v[4] = {x.x, x.y, x.z, x.w};
-        const bool keep = !p.rowmask_out || p.rowmask_out[m];
-        const float* rv = p.rowvec ? p.rowvec + (long)p.row_sample[m] * p.rowvec_ld : nullptr;
-        float* o = out + (long)m * p.ldo + n;
-        const bool vec = (n + 3 < p.N) && !(p.ldo & 3) && (!p.res1 || !(p.ldr1 & 3)) && (!p.res2 || !(p.ldr2 & 3));
-        if (vec) {
-          float r1[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0};
-          if (p.res1) { const float4 t = *reinterpret_cast<const float4*>(p.res1 + (long)m * p.ldr1 + n); r1[0] = t.x; r1[1] = t.y; r1[2] = t.z; r1[3] = t.w; }
-          if (p.res2) { const float4 t = *reinterpret_cast<const float4*>(p.res2 + (long)m * p.ldr2 + n); r2[0] = t.x; r2[1] = t.y; r2[2] = t.z; r2[3] = t.w; }
-          if (p.accumulate) { const float4 t = *reinterpret_cast<const float4*>(o); pv[0] = t.x; pv[1] = t.y; pv[2] = t.z; pv[3] = t.w; }
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int row = it * RPI + rsub;
+      const int m = m0 + wm * WM + mt * 32 + row;
+      if (m >= p.M || n >= p.N) continue;
+      const f32x4 x = *reinterpret_cast<const f32x4*>(slab + row * ES + col);
+      float v[4] = {x[0], x[1], x[2], x[3]};
+      const bool keep = !p.rowmask_out || p.rowmask_out[m];
+      const float* rv = p.rowvec ? p.rowvec + (long)p.row_sample[m] * p.rowvec_ld : nullptr;
+      float* o = out + (long)m * p.ldo + n;
+      const bool vec = (n + 3 < p.N) && !(p.ldo & 3) && (!p.res1 || !(p.ldr1 & 3)) && (!p.res2 || !(p.ldr2 & 3));
+      if (vec) {
+        f32x4 r1 = zero4, r2 = zero4, pv = zero4, bb = zero4;
+        if (p.res1) r1 = *reinterpret_cast<const f32x4*>(p.res1 + (long)m * p.ldr1 + n);
+        if (p.res2) r2 = *reinterpret_cast<const f32x4*>(p.res2 + (long)m * p.ldr2 + n);
+        if (p.accumulate) pv = *reinterpret_cast<const f32x4*>(o);
+        if (p.bias) bb = *reinterpret_cast<const f32x4*>(p.bias + n);
+        f32x4 res;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float t = act_apply(v[e] + (p.bias ? p.bias[n + e] : 0.f), p.act);
-            if (!keep) t = 0.f;
-            if (rv) t += rv[n + e];
-            if (p.res1) t += r1[e];
-            if (p.res2) t += r2[e];
-            t *= p.out_scale;
-            if (p.accumulate) t += pv[e];
-            v[e] = t;
-          }
-          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
+        for (int e = 0; e < 4; ++e) {
+          float t = act_apply(v[e] + bb[e], p.act);
+          if (!keep) t = 0.f;
+          if (rv) t += rv[n + e];
+          if (p.res1) t += r1[e];
+          if (p.res2) t += r2[e];
+          t *= p.out_scale;
+          if (p.accumulate) t += pv[e];
+          res[e] = t;
+        }
+        *reinterpret_cast<f32x4*>(o) = res;
+      } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (n + e >= p.N) continue;
-            float t = act_apply(v[e] + (p.bias ? p.bias[n + e] : 0.f), p.act);
-            if (!keep) t = 0.f;
-            if (rv) t += rv[n + e];
-            if (p.res1) t += p.res1[(long)m * p.ldr1 + n + e];
-            if (p.res2) t += p.res2[(long)m * p.ldr2 + n + e];
-            t *= p.out_scale;
-            if (p.accumulate) t += o[e];
-            o[e] = t;
-          }
+        for (int e = 0; e < 4; ++e) {
+          if (n + e >= p.N) continue;
+          float t = act_apply(v[e] + (p.bias ? p.bias[n + e] : 0.f), p.act);
+          if (!keep) t = 0.f;
+          if (rv) t += rv[n + e];
+          if (p.res1) t += p.res1[(long)m * p.ldr1 + n + e];
+          if (p.res2) t += p.res2[(long)m * p.ldr2 + n + e];
+          t *= p.out_scale;
+          if (p.accumulate) t += o[e];
+          o[e] = t;
         }
       }
-    };
-    pass(std::integral_constant<int, 0>{});
-    if constexpr (MT > 1) pass(std::integral_constant<int, 1>{});
-  } else {
-    // LayerNorm over the 256 output columns: 32 rows at a time through LDS, 8 threads per row.
-    static_assert(!LN || (BN == 256 && BM == WM), "LN variant: one workgroup owns whole 256-wide rows");
-    const int row = tid >> 3, sub = tid & 7;
-    auto pass = [&](auto mt_tag) {
-      constexpr int mt = decltype(mt_tag)::value;
-      __syncthreads();
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int nl = wn * WN + nt * 32 + r32;
-        const float bn = p.bias ? p.bias[nl] : 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) smem[((e & 3) + 8 * (e >> 2) + 4 * half) * LN_STRIDE + nl] = acc[mt][nt][e] + bn;
-      }
-      __syncthreads();
-      float4 x[8];
-      float sum = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        x[i] = *reinterpret_cast<const float4*>(smem + row * LN_STRIDE + 32 * i + 4 * sub);
-        sum += (x[i].x + x[i].y) + (x[i].z + x[i].w);
-      }
-      sum += __shfl_xor(sum, 1);
-      sum += __shfl_xor(sum, 2);
-      sum += __shfl_xor(sum, 4);
-      const float mean = sum * (1.f / 256.f);
-      float sq = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float a = x[i].x - mean, b = x[i].y - mean, cc = x[i].z - mean, d = x[i].w - mean;
-        sq += (a * a + b * b) + (cc * cc + d * d);
-      }
-      sq += __shfl_xor(sq, 1);
-      sq += __shfl_xor(sq, 2);
-      sq += __shfl_xor(sq, 4);
-      const float rstd = 1.0f / sqrtf(sq * (1.f / 256.f) + p.ln_eps);
-      const int m = m0 + mt * 32 + row;
-      if (m < p.M) {
-        const bool keep = !p.rowmask_out || p.rowmask_out[m];
-        const float* rv = p.rowvec ? p.rowvec + (long)p.row_sample[m] * p.rowvec_ld : nullptr;
-#pragma unroll 1
-        for (int i = 0; i < 8; ++i) {
-          const int n = 32 * i + 4 * sub;
-          const float4 xi = *reinterpret_cast<const float4*>(smem + row * LN_STRIDE + n);
-          const float4 g = *reinterpret_cast<const float4*>(p.ln_g + n);
-          const float4 be = *reinterpret_cast<const float4*>(p.ln_b + n);
-          float v[4] = {(xi.x - mean) * rstd * g.x + be.x, (xi.y - mean) * rstd * g.y + be.y,
-                        (xi.z - mean) * rstd * g.z + be.z, (xi.w - mean) * rstd * g.w + be.w};
-          float r1[4] = {0, 0, 0, 0};
-          if (p.res1) { const float4 t = *reinterpret_cast<const float4*>(p.res1 + (long)m * p.ldr1 + n); r1[0] = t.x; r1[1] = t.y; r1[2] = t.z; r1[3] = t.w; }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float t = act_apply(v[e], p.act);
-            if (!keep) t = 0.f;
-            if (rv) t += rv[n + e];
-            if (p.res1) t += r1[e];
-            v[e] = t * p.out_scale;
-          }
-          *reinterpret_cast<float4*>(out + (long)m * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-      }
-    };
-    pass(std::integral_constant<int, 0>{});
-    if constexpr (MT > 1) pass(std::integral_constant<int, 1>{});
-  }
+    }
+  };
+  pass(std::integral_constant<int, 0>{});
+  if constexpr (MT > 1) pass(std::integral_constant<int, 1>{});
 }
 
 void conv_gemm_defaults(ConvGemmArgs& a) {
@@ -320,20 +275,29 @@ void conv_gemm_defaults(ConvGemmArgs& a) {
 
 namespace {
 
-template <int BM, int BN, int WM, int WN, int NAMAX, bool LN, int PRO>
+constexpr size_t LDS_BUDGET = 80 * 1024;   // two workgroups per CU
+
+template <int BM, int BN>
+size_t lds_bytes(const ConvGemmArgs& a) {
+  const int win = BM + (a.ntaps - 1) * a.tap_dil;
+  return (size_t)2 * (win + BN) * LDS_STRIDE * sizeof(float);
+}
+
+template <int BM, int BN, int WM, int WN, int NAMAX, int PRO>
 int launch1(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
   const int win = BM + (a.ntaps - 1) * a.tap_dil;
   if (win > 32 * NAMAX) return fail(JV_ERR_ARG, "conv_gemm: window too tall for this tile variant");
-  size_t lds = (size_t)(win + BN) * LDS_STRIDE * sizeof(float);
-  const size_t need = LN ? (size_t)32 * LN_STRIDE * sizeof(float) : (size_t)4 * 32 * (WN + 4) * sizeof(float);
+  size_t lds = lds_bytes<BM, BN>(a);
+  const size_t need = (size_t)4 * 32 * (WN + 4) * sizeof(float);
   if (lds < need) lds = need;
-  dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), nbatch);
+  const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
+  dim3 grid(tiles_m * tiles_n, 1, nbatch);
   const bool prof = prof_on();
   if (prof) prof_begin(st);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, NAMAX, LN, PRO>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, NAMAX, PRO>), grid, dim3(256), lds, st, a, tiles_n);
   if (prof) {
     static const std::string name = std::string("conv_gemm<") + std::to_string(BM) + "x" + std::to_string(BN) +
-                                    (LN ? ",ln" : "") + (PRO == PRO_SNAKE ? ",snake" : PRO == PRO_LRELU ? ",lrelu" : "") + ">";
+                                    (PRO == PRO_SNAKE ? ",snake" : PRO == PRO_LRELU ? ",lrelu" : "") + ">";
     const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M) * nbatch;
     const double k = (double)(a.alg_k > 0 ? a.alg_k : a.ntaps * a.Cin);
     // algorithmic traffic: A rows once, W once, out once (+ residual reads), fp32
@@ -347,25 +311,25 @@ int launch1(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
 template <int BM, int BN, int WM, int WN, int NAMAX>
 int launch(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
   switch (a.pro) {
-    case PRO_NONE: return launch1<BM, BN, WM, WN, NAMAX, false, PRO_NONE>(a, nbatch, st);
-    case PRO_SNAKE: return launch1<BM, BN, WM, WN, NAMAX, false, PRO_SNAKE>(a, nbatch, st);
-    case PRO_LRELU: return launch1<BM, BN, WM, WN, NAMAX, false, PRO_LRELU>(a, nbatch, st);
+    case PRO_NONE: return launch1<BM, BN, WM, WN, NAMAX, PRO_NONE>(a, nbatch, st);
+    case PRO_SNAKE: return launch1<BM, BN, WM, WN, NAMAX, PRO_SNAKE>(a, nbatch, st);
+    case PRO_LRELU: return launch1<BM, BN, WM, WN, NAMAX, PRO_LRELU>(a, nbatch, st);
     default: return fail(JV_ERR_ARG, "conv_gemm: unknown prologue");
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NAMAX, bool LN, int PRO>
+template <int BM, int BN, int WM, int WN, int NAMAX, int PRO>
 int raise_lds() {
-  JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, NAMAX, LN, PRO>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, NAMAX, PRO>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   return JV_OK;
 }
 
 template <int BM, int BN, int WM, int WN, int NAMAX>
 int raise_lds3() {
-  JV_TRY((raise_lds<BM, BN, WM, WN, NAMAX, false, PRO_NONE>()));
-  JV_TRY((raise_lds<BM, BN, WM, WN, NAMAX, false, PRO_SNAKE>()));
-  JV_TRY((raise_lds<BM, BN, WM, WN, NAMAX, false, PRO_LRELU>()));
+  JV_TRY((raise_lds<BM, BN, WM, WN, NAMAX, PRO_NONE>()));
+  JV_TRY((raise_lds<BM, BN, WM, WN, NAMAX, PRO_SNAKE>()));
+  JV_TRY((raise_lds<BM, BN, WM, WN, NAMAX, PRO_LRELU>()));
   return JV_OK;
 }
 
@@ -375,7 +339,6 @@ int conv_gemm_init() {
   JV_TRY((raise_lds3<128, 128, 64, 64, 6>()));
   JV_TRY((raise_lds3<64, 128, 32, 64, 4>()));
   JV_TRY((raise_lds3<64, 64, 32, 32, 4>()));
-  JV_TRY((raise_lds<64, 256, 64, 64, 3, true, PRO_NONE>()));
   return JV_OK;
 }
 
@@ -387,21 +350,29 @@ int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
   if (a.n_rows_w < a.N) return fail(JV_ERR_ARG, "conv_gemm: weight has fewer rows than N");
   if (a.rowvec && !a.row_sample) return fail(JV_ERR_ARG, "conv_gemm: rowvec needs row_sample");
   if (a.ln) {
-    if (a.N != 256 || nbatch != 1 || a.res2 || a.accumulate || (a.ldo & 3) || (a.res1 && (a.ldr1 & 3)))
-      return fail(JV_ERR_ARG, "conv_gemm: LayerNorm epilogue supports N == 256 only");
-    if (a.pro != PRO_NONE) return fail(JV_ERR_ARG, "conv_gemm: LayerNorm variant has no prologue");
-    return launch1<64, 256, 64, 64, 3, true, PRO_NONE>(a, 1, st);
+    // conv + bias into `out`, then one bandwidth-bound pass: LayerNorm over the N columns, activation, mask,
+    // per-utterance vector, residual.  (A fused 64x256 LayerNorm tile ran at 53 TFLOP/s in round 1 -- slower than the
+    // plain tile plus this 10 us pass -- and cannot double-buffer its 256-row weight tile within two workgroups per CU.)
+    if (nbatch != 1 || a.res2 || a.accumulate || a.ldo != a.N || (a.N & 3) || a.N > 1024)
+      return fail(JV_ERR_ARG, "conv_gemm: LayerNorm epilogue needs a contiguous [M,N] output, N % 4 == 0, N <= 1024");
+    ConvGemmArgs g = a;
+    g.ln = 0; g.act = ACT_NONE; g.rowmask_out = nullptr; g.rowvec = nullptr; g.res1 = nullptr; g.out_scale = 1.f;
+    JV_TRY(conv_gemm(g, 1, st));
+    return ln_epilogue_rows(a.out, a.ln_g, a.ln_b, a.ln_eps, a.M, a.N, a.act, a.rowmask_out, a.rowvec, a.row_sample,
+                            a.rowvec_ld, a.res1, a.ldr1, a.out_scale, st);
   }
-  // Tile choice: the kernel is MFMA-bound, so cost ~ (#workgroup waves over 256 CUs) x tile area,
-  // with a mild penalty for the smaller tiles' lower operand reuse.
+  // Tile choice: the kernel is MFMA-bound, so cost ~ (#workgroup waves over 256 CUs) x tile area, with a mild penalty
+  // for the smaller tiles' lower operand reuse; a variant must fit two workgroups' double-buffered LDS on a CU.
   const int span = (a.ntaps - 1) * a.tap_dil;
-  struct Cand { int bm, bn; double eff; };
-  const Cand cands[3] = {{128, 128, 1.0}, {64, 128, 0.93}, {64, 64, 0.85}};
+  struct Cand { int bm, bn; double eff; size_t lds; };
+  const Cand cands[3] = {{128, 128, 1.0, lds_bytes<128, 128>(a)}, {64, 128, 0.95, lds_bytes<64, 128>(a)},
+                         {64, 64, 0.88, lds_bytes<64, 64>(a)}};
   int best = -1;
   double best_cost = 0;
   for (int i = 0; i < 3; ++i) {
     if (i == 0 && 128 + span > 192) continue;
     if (i > 0 && 64 + span > 128) continue;
+    if (cands[i].lds > LDS_BUDGET && i < 2) continue;
     const long tiles = (long)cdiv(a.M, cands[i].bm) * cdiv(a.N, cands[i].bn) * nbatch;
     const double cost = (double)cdivl(tiles, 256) * cands[i].bm * cands[i].bn / cands[i].eff;
     if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }

@@ -18,6 +18,9 @@ int assemble_xin_plain(const float* x, const float* mu, const float* spks, const
 int time_sinusoid(const float* t, int t_stride, float* out, int B, hipStream_t st);
 int euler_cfg(float* x, const float* d, int B, int G, int S, int L, const float* dt_table, int step, float rate,
               hipStream_t st);
+int ln_epilogue_rows(float* x, const float* g, const float* b, float eps, long rows, int C, int act,
+                     const unsigned char* rowmask, const float* rowvec, const int* row_sample, int rowvec_ld, const float* res,
+                     long ldr, float scale, hipStream_t st);
 int fill(float* p, float v, long n, hipStream_t st);
 int fill_int(int* p, int v, long n, hipStream_t st);
 

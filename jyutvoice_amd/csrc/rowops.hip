@@ -3,6 +3,7 @@
 #include <math.h>
 
 #include "jv_common.h"
+#include "jv_device.h"
 #include "jv_ops.h"
 
 namespace jv {
@@ -74,6 +75,78 @@ int layernorm_rows(const float* x, const float* add, float* out, const float* g,
     hipLaunchKernelGGL((layernorm_rows_kernel<3>), grid, dim3(256), 0, st, x, add, out, g, b, eps, rows, C, rowmask_out, relu);
   else
     hipLaunchKernelGGL((layernorm_rows_kernel<4>), grid, dim3(256), 0, st, x, add, out, g, b, eps, rows, C, rowmask_out, relu);
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+// ---- LayerNorm epilogue of a convolution, in place: x = (act(LN(x)) * mask + rowvec[sample] + res) * scale ----------
+// (CausalBlock1D's conv -> LayerNorm -> Mish -> mask, the resnet's time-embedding add and residual; decoder.py:784-788,
+// 110-115).  One wave per row, C <= 1024, 16 B per lane.
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_epilogue_kernel(float* __restrict__ x, const float* __restrict__ g,
+                                                          const float* __restrict__ b, float eps, long rows, int C, int act,
+                                                          const unsigned char* __restrict__ rowmask,
+                                                          const float* __restrict__ rowvec, const int* __restrict__ row_sample,
+                                                          int rowvec_ld, const float* __restrict__ res, long ldr, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c4n = C >> 2;
+  f32x4 v[VPL];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c4 = lane + 64 * i;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < c4n) t = *reinterpret_cast<const f32x4*>(x + row * C + 4 * c4);
+    v[i] = t;
+    sum += (t[0] + t[1]) + (t[2] + t[3]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    if (lane + 64 * i < c4n) {
+      const f32x4 d = v[i] - mean;
+      sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+  const bool keep = !rowmask || rowmask[row];
+  const float* rv = rowvec ? rowvec + (long)row_sample[row] * rowvec_ld : nullptr;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < c4n) {
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * c4);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 4 * c4);
+      f32x4 r = (v[i] - mean) * rstd * gg + bb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = keep ? act_apply(r[e], act) : 0.f;
+      if (rv) r += *reinterpret_cast<const f32x4*>(rv + 4 * c4);
+      if (res) r += *reinterpret_cast<const f32x4*>(res + row * ldr + 4 * c4);
+      *reinterpret_cast<f32x4*>(x + row * C + 4 * c4) = r * scale;
+    }
+  }
+}
+
+int ln_epilogue_rows(float* x, const float* g, const float* b, float eps, long rows, int C, int act,
+                     const unsigned char* rowmask, const float* rowvec, const int* row_sample, int rowvec_ld, const float* res,
+                     long ldr, float scale, hipStream_t st) {
+  if (rows <= 0) return JV_OK;
+  if ((C & 3) || C > 1024 || (rowvec && (rowvec_ld & 3)) || (res && (ldr & 3)))
+    return fail(JV_ERR_ARG, "ln_epilogue_rows: C, rowvec_ld and ldr must be multiples of 4 (C <= 1024)");
+  const dim3 grid((unsigned)cdivl(rows, 4));
+  if (C <= 256)
+    hipLaunchKernelGGL((ln_epilogue_kernel<1>), grid, dim3(256), 0, st, x, g, b, eps, rows, C, act, rowmask, rowvec, row_sample,
+                       rowvec_ld, res, ldr, scale);
+  else
+    hipLaunchKernelGGL((ln_epilogue_kernel<4>), grid, dim3(256), 0, st, x, g, b, eps, rows, C, act, rowmask, rowvec, row_sample,
+                       rowvec_ld, res, ldr, scale);
   JV_HIP(hipGetLastError());
   return JV_OK;
 }
