@@ -26,8 +26,12 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <stdio.h>
+
+#include <algorithm>
 #include <string>
 #include <type_traits>
+#include <vector>
 
 #include "jv_common.h"
 #include "jv_device.h"
@@ -40,7 +44,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LDS_STRIDE = 36;
 
-template <int BM, int BN, int WM, int WN, int NAMAX, int PRO>
+// EPI: bit 0 = exact GELU, bit 1 = + res1 (lean float4 epilogues); 4 = generic (any activation, mask, row vector,
+// second residual, scaling, accumulation, ragged N)
+template <int BM, int BN, int WM, int WN, int NAMAX, int PRO, int EPI>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = WM / 32, NT = WN / 32;
@@ -73,6 +79,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p, co
     out += z1 * p.sO1 + z2 * p.sO2;
   }
 
+  unsigned long long t_start = 0, t_loop = 0, t_epi = 0, t_loop2 = 0, t_p0 = 0;
+  if (p.stamps) t_start = __builtin_amdgcn_s_memtime();
   const int ntaps = p.ntaps, dil = p.tap_dil;
   const int win = BM + (ntaps - 1) * dil;
   const int na = (win + 31) >> 5;
@@ -169,6 +177,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p, co
   // ---- main loop: step s = (chunk c, tap j); registers hold exactly one pending A window and one pending W tile ----
   const int nchunks = p.Cin >> 5;
   const int nsteps = nchunks * ntaps;
+  // De-phase the workgroups that share a CU: all blocks start together, run equally long main loops and would reach
+  // their (HBM-write-bound) epilogues together, leaving the matrix pipe idle.  Blocks of the second dispatch wave
+  // start half a tile late, so one workgroup's epilogue/prologue runs under the other's MFMAs from then on.
+  if ((p.ablate & 32) && blockIdx.x >= 256 && blockIdx.x < 512) {
+    const int naps = (nsteps * MT * NT * 1024) / 8128 / 2 + 1;     // ~half of this tile's MFMA time
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   load_A(0);
   load_W(0, 0);
   store_A(0, 0);
@@ -177,6 +192,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p, co
   if (ntaps == 1 && nchunks > 1) load_A(32);                          // A of chunk 1 is stored during step 0
   __syncthreads();
 
+  if (p.stamps) t_loop = __builtin_amdgcn_s_memtime();
   int c = 0, j = 0;
   for (int s = 0; s < nsteps; ++s) {
     const float* la = ldsA0 + (c & 1) * win * LDS_STRIDE + (wm * WM + r32 + j * dil) * LDS_STRIDE + 16 * half;
@@ -186,22 +202,44 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p, co
     int j1 = j + 1, c1 = c;                      // step s+1
     if (j1 == ntaps) { j1 = 0; c1 = c + 1; }
     if (s + 1 < nsteps) {
-      store_W((s + 1) & 1);
-      if (j == ntaps - 1) store_A(c1 * 32, c1 & 1);
+      if (!(p.ablate & 2)) {
+        store_W((s + 1) & 1);
+        if (j == ntaps - 1) store_A(c1 * 32, c1 & 1);
+      }
       int j2 = j1 + 1, c2 = c1;                  // step s+2
       if (j2 == ntaps) { j2 = 0; c2 = c1 + 1; }
-      if (s + 2 < nsteps) load_W(j2, c2 * 32);
-      if (j1 == ntaps - 1 && c1 + 1 < nchunks) load_A((c1 + 1) * 32);   // stored during step s+1
+      if (!(p.ablate & 1)) {
+        if (s + 2 < nsteps) load_W(j2, c2 * 32);
+        if (j1 == ntaps - 1 && c1 + 1 < nchunks) load_A((c1 + 1) * 32);   // stored during step s+1
+      }
     }
     mfma_quads(la, lw, 2);
-    __syncthreads();
+    if (!(p.ablate & 4)) __syncthreads();
     j = j1;
     c = c1;
   }
 
-  // ---- epilogue: accumulators -> per-wave LDS slab (32 rows per pass) -> rolled, float4-coalesced finish ----------
+  // ---- epilogue: accumulators -> per-wave LDS slab (32 rows per pass) -> float4-coalesced finish ----------------
+  // Per-row operands (mask, residuals, previous value) of four rows are fetched together before any arithmetic: a
+  // rolled row loop would expose one global-load latency per row (measured: 33 K cycles per 128x128 tile).
+  if (p.stamps) t_epi = __builtin_amdgcn_s_memtime();
+  if (p.ablate & 16) return;
   constexpr int ES = WN + 4;
+  constexpr int C4 = WN / 4;                     // float4 columns per row
+  constexpr int RPI = 64 / C4;                   // rows per wave-instruction
+  constexpr int NIT = 32 / RPI;                  // row groups per 32-row pass
+  constexpr int UN = NIT < 4 ? NIT : 4;
   float* slab = smem + wave * 32 * ES;
+  const int col = (lane % C4) * 4, rsub = lane / C4;
+  const int n = n0 + wn * WN + col;
+  const bool nin = n < p.N;
+  const bool vec = (n + 3 < p.N) && !(p.ldo & 3) && (!p.res1 || !(p.ldr1 & 3)) && (!p.res2 || !(p.ldr2 & 3));
+  f32x4 bb = zero4;
+  if (p.bias && nin) {
+    if (n + 3 < p.N) bb = *reinterpret_cast<const f32x4*>(p.bias + n);
+    else
+      for (int e = 0; e < 4; ++e) bb[e] = (n + e < p.N) ? p.bias[n + e] : 0.f;
+  }
   auto pass = [&](auto mt_tag) {
     constexpr int mt = decltype(mt_tag)::value;
     if (mt > 0) __syncthreads();
@@ -210,58 +248,102 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p, co
 #pragma unroll
       for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * half) * ES + nt * 32 + r32] = acc[mt][nt][e];
     __syncthreads();
-    constexpr int C4 = WN / 4;                     // float4 columns per row
-    constexpr int RPI = 64 / C4;                   // rows per iteration
-    const int col = (lane % C4) * 4, rsub = lane / C4;
-    const int n = n0 + wn * WN + col;
+    if (p.stamps && mt == 0) t_loop2 = __builtin_amdgcn_s_memtime();
+    if constexpr (EPI != 4) {
+      // lean path (host guarantees N % 4 == 0, 16-byte aligned rows, no mask / row vector / second residual / scaling):
+      // out = act(acc + bias) (+ res1).  All residual loads of the pass are issued before any arithmetic.
+      constexpr bool E_GELU = (EPI & 1) != 0, E_RES = (EPI & 2) != 0;
+      const int mrow = m0 + wm * WM + mt * 32 + rsub;
+      f32x4 x[NIT], r[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) x[it] = *reinterpret_cast<const f32x4*>(slab + (it * RPI + rsub) * ES + col);
+      if constexpr (E_RES) {
+        const float* rb = p.res1 + (long)mrow * p.ldr1 + n;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          r[it] = (nin && mrow + it * RPI < p.M) ? *reinterpret_cast<const f32x4*>(rb + (long)(it * RPI) * p.ldr1) : zero4;
+      }
+      float* ob = out + (long)mrow * p.ldo + n;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        f32x4 t = x[it] + bb;
+        if constexpr (E_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = 0.5f * t[e] * (1.f + erff(t[e] * 0.70710678118654752440f));
+        }
+        if constexpr (E_RES) t += r[it];
+        if (nin && mrow + it * RPI < p.M && !(p.ablate & 64)) *reinterpret_cast<f32x4*>(ob + (long)(it * RPI) * p.ldo) = t;
+      }
+      return;
+    }
 #pragma unroll 1
-    for (int it = 0; it < 32 / RPI; ++it) {
-      const int row = it * RPI + rsub;
-      const int m = m0 + wm * WM + mt * 32 + row;
-      if (m >= p.M || n >= p.N) continue;
-      const f32x4 x = *reinterpret_cast<const f32x4*>(slab + row * ES + col);
-      float v[4] = {x[0], x[1], x[2], x[3]};
-      const bool keep = !p.rowmask_out || p.rowmask_out[m];
-      const float* rv = p.rowvec ? p.rowvec + (long)p.row_sample[m] * p.rowvec_ld : nullptr;
-      float* o = out + (long)m * p.ldo + n;
-      const bool vec = (n + 3 < p.N) && !(p.ldo & 3) && (!p.res1 || !(p.ldr1 & 3)) && (!p.res2 || !(p.ldr2 & 3));
-      if (vec) {
-        f32x4 r1 = zero4, r2 = zero4, pv = zero4, bb = zero4;
-        if (p.res1) r1 = *reinterpret_cast<const f32x4*>(p.res1 + (long)m * p.ldr1 + n);
-        if (p.res2) r2 = *reinterpret_cast<const f32x4*>(p.res2 + (long)m * p.ldr2 + n);
-        if (p.accumulate) pv = *reinterpret_cast<const f32x4*>(o);
-        if (p.bias) bb = *reinterpret_cast<const f32x4*>(p.bias + n);
+    for (int it0 = 0; it0 < NIT; it0 += UN) {
+      f32x4 x[UN], r1[UN], r2[UN], pv[UN];
+      bool ok[UN], keep[UN];
+      int sample[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int row = (it0 + u) * RPI + rsub;
+        const int m = m0 + wm * WM + mt * 32 + row;
+        ok[u] = nin && m < p.M;
+        x[u] = *reinterpret_cast<const f32x4*>(slab + row * ES + col);
+        r1[u] = zero4; r2[u] = zero4; pv[u] = zero4;
+        keep[u] = true;
+        sample[u] = 0;
+        if (ok[u]) {
+          if (p.rowmask_out) keep[u] = p.rowmask_out[m] != 0;
+          if (p.rowvec) sample[u] = p.row_sample[m];
+          if (vec) {
+            if (p.res1) r1[u] = *reinterpret_cast<const f32x4*>(p.res1 + (long)m * p.ldr1 + n);
+            if (p.res2) r2[u] = *reinterpret_cast<const f32x4*>(p.res2 + (long)m * p.ldr2 + n);
+            if (p.accumulate) pv[u] = *reinterpret_cast<const f32x4*>(out + (long)m * p.ldo + n);
+          } else {
+            for (int e = 0; e < 4; ++e) {
+              if (n + e < p.N) {
+                if (p.res1) r1[u][e] = p.res1[(long)m * p.ldr1 + n + e];
+                if (p.res2) r2[u][e] = p.res2[(long)m * p.ldr2 + n + e];
+                if (p.accumulate) pv[u][e] = out[(long)m * p.ldo + n + e];
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (!ok[u]) continue;
+        const int row = (it0 + u) * RPI + rsub;
+        const int m = m0 + wm * WM + mt * 32 + row;
+        f32x4 rvv = zero4;
+        if (p.rowvec) {
+          const float* rv = p.rowvec + (long)sample[u] * p.rowvec_ld + n;
+          for (int e = 0; e < 4; ++e) rvv[e] = (n + e < p.N) ? rv[e] : 0.f;
+        }
         f32x4 res;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float t = act_apply(v[e] + bb[e], p.act);
-          if (!keep) t = 0.f;
-          if (rv) t += rv[n + e];
-          if (p.res1) t += r1[e];
-          if (p.res2) t += r2[e];
-          t *= p.out_scale;
-          if (p.accumulate) t += pv[e];
-          res[e] = t;
+          float t = act_apply(x[u][e] + bb[e], p.act);
+          if (!keep[u]) t = 0.f;
+          t = ((t + rvv[e]) + r1[u][e]) + r2[u][e];
+          res[e] = t * p.out_scale + pv[u][e];
         }
-        *reinterpret_cast<f32x4*>(o) = res;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (n + e >= p.N) continue;
-          float t = act_apply(v[e] + (p.bias ? p.bias[n + e] : 0.f), p.act);
-          if (!keep) t = 0.f;
-          if (rv) t += rv[n + e];
-          if (p.res1) t += p.res1[(long)m * p.ldr1 + n + e];
-          if (p.res2) t += p.res2[(long)m * p.ldr2 + n + e];
-          t *= p.out_scale;
-          if (p.accumulate) t += o[e];
-          o[e] = t;
+        float* o = out + (long)m * p.ldo + n;
+        if (vec) {
+          if (!(p.ablate & 64) || res[0] == 12345.678f) *reinterpret_cast<f32x4*>(o) = res;
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) o[e] = res[e];
         }
       }
     }
   };
   pass(std::integral_constant<int, 0>{});
+  if (p.stamps) t_p0 = __builtin_amdgcn_s_memtime();
   if constexpr (MT > 1) pass(std::integral_constant<int, 1>{});
+  if (p.stamps && tid == 0) {
+    unsigned long long* d = p.stamps + (size_t)blockIdx.x * 4;
+    d[0] = t_start; d[1] = t_loop; d[2] = t_epi; d[3] = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 300) printf("[wg300] drain+slab %llu  rows-pass0 %llu  pass1 %llu\n", t_loop2 - t_epi, t_p0 - t_loop2, d[3] - t_p0);
+  }
 }
 
 void conv_gemm_defaults(ConvGemmArgs& a) {
@@ -283,8 +365,8 @@ size_t lds_bytes(const ConvGemmArgs& a) {
   return (size_t)2 * (win + BN) * LDS_STRIDE * sizeof(float);
 }
 
-template <int BM, int BN, int WM, int WN, int NAMAX, int PRO>
-int launch1(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int NAMAX, int PRO, int EPI>
+int launch2(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
   const int win = BM + (a.ntaps - 1) * a.tap_dil;
   if (win > 32 * NAMAX) return fail(JV_ERR_ARG, "conv_gemm: window too tall for this tile variant");
   size_t lds = lds_bytes<BM, BN>(a);
@@ -294,10 +376,32 @@ int launch1(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
   dim3 grid(tiles_m * tiles_n, 1, nbatch);
   const bool prof = prof_on();
   if (prof) prof_begin(st);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, NAMAX, PRO>), grid, dim3(256), lds, st, a, tiles_n);
+  if (getenv("JV_STAMPS")) {   // diagnostic only: synchronous, prints phase shares of this launch
+    static unsigned long long* dbuf = nullptr;
+    const size_t nb = (size_t)grid.x * 4;
+    if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 4 * 65536);
+    ConvGemmArgs b = a;
+    b.stamps = grid.x <= 65536 ? dbuf : nullptr;
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, NAMAX, PRO, EPI>), grid, dim3(256), lds, st, b, tiles_n);
+    (void)hipStreamSynchronize(st);
+    if (b.stamps) {
+      std::vector<unsigned long long> h(nb);
+      (void)hipMemcpy(h.data(), dbuf, nb * 8, hipMemcpyDeviceToHost);
+      double pro = 0, loop = 0, epi = 0, first = 1e300, last = 0;
+      for (unsigned i = 0; i < grid.x; ++i) {
+        pro += (double)(h[4 * i + 1] - h[4 * i]); loop += (double)(h[4 * i + 2] - h[4 * i + 1]); epi += (double)(h[4 * i + 3] - h[4 * i + 2]);
+        first = std::min(first, (double)h[4 * i]); last = std::max(last, (double)h[4 * i + 3]);
+      }
+      fprintf(stderr, "[stamps] %dx%d grid %u: prologue %.0f  loop %.0f  epilogue %.0f cycles avg per workgroup; kernel span %.0f cycles\n",
+              BM, BN, grid.x, pro / grid.x, loop / grid.x, epi / grid.x, last - first);
+    }
+    return JV_OK;
+  }
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, NAMAX, PRO, EPI>), grid, dim3(256), lds, st, a, tiles_n);
   if (prof) {
     static const std::string name = std::string("conv_gemm<") + std::to_string(BM) + "x" + std::to_string(BN) +
-                                    (PRO == PRO_SNAKE ? ",snake" : PRO == PRO_LRELU ? ",lrelu" : "") + ">";
+                                    (PRO == PRO_SNAKE ? ",snake" : PRO == PRO_LRELU ? ",lrelu" : "") +
+                                    (EPI == 1 ? ",gelu" : EPI == 2 ? ",res" : EPI == 4 ? ",generic" : "") + ">";
     const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M) * nbatch;
     const double k = (double)(a.alg_k > 0 ? a.alg_k : a.ntaps * a.Cin);
     // algorithmic traffic: A rows once, W once, out once (+ residual reads), fp32
@@ -306,6 +410,16 @@ int launch1(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
   }
   JV_HIP(hipGetLastError());
   return JV_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int NAMAX, int PRO>
+int launch1(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
+  const bool lean = !(a.N & 3) && !(a.ldo & 3) && (!a.res1 || !(a.ldr1 & 3)) && !a.res2 && !a.rowvec && !a.rowmask_out &&
+                    !a.accumulate && a.out_scale == 1.f && !getenv("JV_GENERIC_EPI");
+  if (lean && a.act == ACT_NONE)
+    return a.res1 ? launch2<BM, BN, WM, WN, NAMAX, PRO, 2>(a, nbatch, st) : launch2<BM, BN, WM, WN, NAMAX, PRO, 0>(a, nbatch, st);
+  if (lean && a.act == ACT_GELU && PRO == PRO_NONE && !a.res1) return launch2<BM, BN, WM, WN, NAMAX, PRO_NONE, 1>(a, nbatch, st);
+  return launch2<BM, BN, WM, WN, NAMAX, PRO, 4>(a, nbatch, st);
 }
 
 template <int BM, int BN, int WM, int WN, int NAMAX>
@@ -318,10 +432,19 @@ int launch(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
   }
 }
 
+template <int BM, int BN, int WM, int WN, int NAMAX, int PRO, int EPI>
+int raise_lds1() {
+  JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, NAMAX, PRO, EPI>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  return JV_OK;
+}
+
 template <int BM, int BN, int WM, int WN, int NAMAX, int PRO>
 int raise_lds() {
-  JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, NAMAX, PRO>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  JV_TRY((raise_lds1<BM, BN, WM, WN, NAMAX, PRO, 0>()));
+  if (PRO == PRO_NONE) JV_TRY((raise_lds1<BM, BN, WM, WN, NAMAX, PRO_NONE, 1>()));
+  JV_TRY((raise_lds1<BM, BN, WM, WN, NAMAX, PRO, 2>()));
+  JV_TRY((raise_lds1<BM, BN, WM, WN, NAMAX, PRO, 4>()));
   return JV_OK;
 }
 
@@ -377,6 +500,7 @@ int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
     const double cost = (double)cdivl(tiles, 256) * cands[i].bm * cands[i].bn / cands[i].eff;
     if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
   }
+  if (const char* ab = getenv("JV_ABLATE")) const_cast<ConvGemmArgs&>(a).ablate = atoi(ab);
   if (const char* force = getenv("JV_TILE")) {   // tuning aid: force a tile variant (0, 1, 2)
     const int f = atoi(force);
     if (f >= 0 && f <= 2 && !((f == 0 && 128 + span > 192) || (f > 0 && 64 + span > 128))) best = f;

@@ -90,6 +90,8 @@ struct ConvGemmArgs {
   // rows, channel padding or the zero taps of a polyphase transposed conv
   long alg_rows;
   int alg_k;
+  unsigned long long* stamps;   // tuning aid (JV_STAMPS): per-workgroup s_memtime at start / loop / epilogue / end
+  int ablate;   // tuning aid (JV_ABLATE): 1 no global loads in loop, 2 no LDS stores, 4 no barrier, 16 no epilogue
 };
 
 void conv_gemm_defaults(ConvGemmArgs& a);

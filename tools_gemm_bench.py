@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from jyutvoice_amd.engine import op_attention, op_conv_gemm  # noqa: E402
 
 dev = torch.device("cuda:0")
-M = 4 + 64 * 304
+M = int(os.environ.get("JV_M", 4 + 64 * 304))
 g = torch.Generator().manual_seed(0)
 
 
