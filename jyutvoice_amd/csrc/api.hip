@@ -1,4 +1,5 @@
 // extern "C" surface of libjyutvoice_hip.so (include/jyutvoice_hip.h).  Nothing throws across it.
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -8,6 +9,8 @@
 #include "jv_ops.h"
 
 namespace jv {
+
+int split3_planes(const float* src, unsigned short* dst, long n, hipStream_t st);   // registry.hip
 
 static thread_local std::string g_last_error;
 
@@ -189,6 +192,19 @@ int jv_op_conv_gemm(const float* A, int64_t a_rows, int M, int Cin, int ntaps, i
   if (ln_g) { a.ln = 1; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = ln_eps; }
   a.rowmask_in = rowmask; a.rowmask_out = rowmask;
   a.res1 = res; a.ldr1 = N;
+  if (getenv("JV_OP_X6")) {   // exercise the bf16x6 main loop: split W into three bf16 planes on the fly
+    static unsigned short* scratch = nullptr;
+    static size_t cap = 0;
+    const size_t n = (size_t)N * ntaps * Cin;
+    if (3 * n > cap) {
+      if (scratch) (void)hipFree(scratch);
+      JV_HIP(hipMalloc(reinterpret_cast<void**>(&scratch), 3 * n * sizeof(unsigned short) + 64));
+      cap = 3 * n;
+    }
+    JV_TRY(jv::split3_planes(W, scratch, (long)n, static_cast<hipStream_t>(stream)));
+    a.W3 = scratch;
+    a.w3_plane = (long)n;
+  }
   return jv::conv_gemm(a, 1, static_cast<hipStream_t>(stream));
 }
 

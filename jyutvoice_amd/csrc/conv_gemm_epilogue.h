@@ -1,0 +1,151 @@
+// Shared epilogue of the conv_gemm kernels (fp32-MFMA and bf16x6-MFMA main loops produce the same 32x32 accumulator
+// tiles): accumulators -> per-wave LDS slab (32 rows per pass) -> float4-coalesced finish.
+#pragma once
+#include <type_traits>
+
+#include "jv_common.h"
+#include "jv_device.h"
+
+namespace jv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// EPI: bit 0 = exact GELU, bit 1 = + res1 (lean float4 epilogues); 4 = generic (any activation, mask, row vector,
+// second residual, scaling, accumulation, ragged N).  Must be entered by all 256 threads after the main loop's last
+// barrier; `smem` is reused for the slabs.
+template <int WM, int WN, int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out, f32x16 (&acc)[WM / 32][WN / 32], float* smem,
+                                              const int m0, const int n0, const int wm, const int wn,
+                                              unsigned long long t_start, unsigned long long t_loop) {
+  constexpr int MT = WM / 32, NT = WN / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, half = lane >> 5;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  unsigned long long t_epi = 0, t_loop2 = 0, t_p0 = 0;
+  // Per-row operands (mask, residuals, previous value) of four rows are fetched together before any arithmetic: a
+  // rolled row loop would expose one global-load latency per row (measured: 33 K cycles per 128x128 tile).
+  if (p.stamps) t_epi = __builtin_amdgcn_s_memtime();
+  if (p.ablate & 16) return;
+  constexpr int ES = WN + 4;
+  constexpr int C4 = WN / 4;                     // float4 columns per row
+  constexpr int RPI = 64 / C4;                   // rows per wave-instruction
+  constexpr int NIT = 32 / RPI;                  // row groups per 32-row pass
+  constexpr int UN = NIT < 4 ? NIT : 4;
+  float* slab = smem + wave * 32 * ES;
+  const int col = (lane % C4) * 4, rsub = lane / C4;
+  const int n = n0 + wn * WN + col;
+  const bool nin = n < p.N;
+  const bool vec = (n + 3 < p.N) && !(p.ldo & 3) && (!p.res1 || !(p.ldr1 & 3)) && (!p.res2 || !(p.ldr2 & 3));
+  f32x4 bb = zero4;
+  if (p.bias && nin) {
+    if (n + 3 < p.N) bb = *reinterpret_cast<const f32x4*>(p.bias + n);
+    else
+      for (int e = 0; e < 4; ++e) bb[e] = (n + e < p.N) ? p.bias[n + e] : 0.f;
+  }
+  auto pass = [&](auto mt_tag) {
+    constexpr int mt = decltype(mt_tag)::value;
+    if (mt > 0) __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * half) * ES + nt * 32 + r32] = acc[mt][nt][e];
+    __syncthreads();
+    if (p.stamps && mt == 0) t_loop2 = __builtin_amdgcn_s_memtime();
+    if constexpr (EPI != 4) {
+      // lean path (host guarantees N % 4 == 0, 16-byte aligned rows, no mask / row vector / second residual / scaling):
+      // out = act(acc + bias) (+ res1).  All residual loads of the pass are issued before any arithmetic.
+      constexpr bool E_GELU = (EPI & 1) != 0, E_RES = (EPI & 2) != 0;
+      const int mrow = m0 + wm * WM + mt * 32 + rsub;
+      f32x4 x[NIT], r[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) x[it] = *reinterpret_cast<const f32x4*>(slab + (it * RPI + rsub) * ES + col);
+      if constexpr (E_RES) {
+        const float* rb = p.res1 + (long)mrow * p.ldr1 + n;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          r[it] = (nin && mrow + it * RPI < p.M) ? *reinterpret_cast<const f32x4*>(rb + (long)(it * RPI) * p.ldr1) : zero4;
+      }
+      float* ob = out + (long)mrow * p.ldo + n;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        f32x4 t = x[it] + bb;
+        if constexpr (E_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = 0.5f * t[e] * (1.f + erff(t[e] * 0.70710678118654752440f));
+        }
+        if constexpr (E_RES) t += r[it];
+        if (nin && mrow + it * RPI < p.M && !(p.ablate & 64)) *reinterpret_cast<f32x4*>(ob + (long)(it * RPI) * p.ldo) = t;
+      }
+      return;
+    }
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT; it0 += UN) {
+      f32x4 x[UN], r1[UN], r2[UN], pv[UN];
+      bool ok[UN], keep[UN];
+      int sample[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int row = (it0 + u) * RPI + rsub;
+        const int m = m0 + wm * WM + mt * 32 + row;
+        ok[u] = nin && m < p.M;
+        x[u] = *reinterpret_cast<const f32x4*>(slab + row * ES + col);
+        r1[u] = zero4; r2[u] = zero4; pv[u] = zero4;
+        keep[u] = true;
+        sample[u] = 0;
+        if (ok[u]) {
+          if (p.rowmask_out) keep[u] = p.rowmask_out[m] != 0;
+          if (p.rowvec) sample[u] = p.row_sample[m];
+          if (vec) {
+            if (p.res1) r1[u] = *reinterpret_cast<const f32x4*>(p.res1 + (long)m * p.ldr1 + n);
+            if (p.res2) r2[u] = *reinterpret_cast<const f32x4*>(p.res2 + (long)m * p.ldr2 + n);
+            if (p.accumulate) pv[u] = *reinterpret_cast<const f32x4*>(out + (long)m * p.ldo + n);
+          } else {
+            for (int e = 0; e < 4; ++e) {
+              if (n + e < p.N) {
+                if (p.res1) r1[u][e] = p.res1[(long)m * p.ldr1 + n + e];
+                if (p.res2) r2[u][e] = p.res2[(long)m * p.ldr2 + n + e];
+                if (p.accumulate) pv[u][e] = out[(long)m * p.ldo + n + e];
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (!ok[u]) continue;
+        const int row = (it0 + u) * RPI + rsub;
+        const int m = m0 + wm * WM + mt * 32 + row;
+        f32x4 rvv = zero4;
+        if (p.rowvec) {
+          const float* rv = p.rowvec + (long)sample[u] * p.rowvec_ld + n;
+          for (int e = 0; e < 4; ++e) rvv[e] = (n + e < p.N) ? rv[e] : 0.f;
+        }
+        f32x4 res;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = act_apply(x[u][e] + bb[e], p.act);
+          if (!keep[u]) t = 0.f;
+          t = ((t + rvv[e]) + r1[u][e]) + r2[u][e];
+          res[e] = t * p.out_scale + pv[u][e];
+        }
+        float* o = out + (long)m * p.ldo + n;
+        if (vec) {
+          if (!(p.ablate & 64) || res[0] == 12345.678f) *reinterpret_cast<f32x4*>(o) = res;
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) o[e] = res[e];
+        }
+      }
+    }
+  };
+  pass(std::integral_constant<int, 0>{});
+  if (p.stamps) t_p0 = __builtin_amdgcn_s_memtime();
+  if constexpr (MT > 1) pass(std::integral_constant<int, 1>{});
+  if (p.stamps && tid == 0) {
+    unsigned long long* d = p.stamps + (size_t)blockIdx.x * 4;
+    d[0] = t_start; d[1] = t_loop; d[2] = t_epi; d[3] = __builtin_amdgcn_s_memtime();
+  }
+}
+
+}  // namespace jv

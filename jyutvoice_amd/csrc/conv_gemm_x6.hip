@@ -1,0 +1,301 @@
+// conv_gemm with the contraction on the bf16 matrix cores at fp32 accuracy ("bf16x6").
+//
+// Every fp32 operand is split into three bf16 planes x = h + m + l (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m):
+// 24 significant bits) and the product is formed from the six partial products whose weight is >= 2^-16:
+//     x*y ~= h h' + (h m' + m h') + (h l' + l h' + m m')          dropped: m l' + l m' + l l'  (relative 2^-24, 2^-32)
+// Each partial product of two bf16 values is exact in fp32 and the MFMA accumulates in fp32, so the result carries
+// fp32-level error (measured against fp64 in tests/test_gpu_ops.py with the same bounds as the fp32-MFMA kernel), while
+// v_mfma_f32_32x32x16_bf16 delivers a 32x32x16 block in 32 cycles against 8 x 64 cycles for v_mfma_f32_32x32x2_f32:
+// 6 x 32 = 192 vs 512 cycles per 16 k, i.e. 2.67x less matrix-pipe time for the same fp32-accurate contraction.
+//
+// Weights are split once at load time (registry.hip, three bf16 planes in HBM, 6 B per weight); activations are split
+// while the A window is staged into LDS (after the Snake / LeakyReLU / mask prologue), once per workgroup and K-chunk.
+// LDS rows are 80 B (32 bf16 + 16 B pad) so the ds_read_b128 operand fetches (8 consecutive k of one row per lane) are
+// bank-conflict free.  Everything outside the main loop (tile order, masks, epilogue) is shared with conv_gemm.hip.
+#include <math.h>
+#include <stdlib.h>
+
+#include <string>
+
+#include "conv_gemm_epilogue.h"
+#include "jv_common.h"
+#include "jv_device.h"
+#include "jv_ops.h"
+
+namespace jv {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int X6_ROWB = 80;   // bytes per LDS row: 32 bf16 + pad
+
+__device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
+  bf16x8 hh, mm, ll;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    hh[e] = (__bf16)x[e];
+    const float r = x[e] - (float)hh[e];
+    mm[e] = (__bf16)r;
+    ll[e] = (__bf16)(r - (float)mm[e]);
+  }
+  h = __builtin_bit_cast(u32x4, hh);
+  m = __builtin_bit_cast(u32x4, mm);
+  l = __builtin_bit_cast(u32x4, ll);
+}
+
+template <int BM, int BN, int WM, int WN, int PRO, int EPI>
+__global__ __launch_bounds__(256) void conv_gemm_x6_kernel(const ConvGemmArgs p, const int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int MT = WM / 32, NT = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+  constexpr int NA2 = 2;                       // window rows handled per thread: tid>>1 + 128*i
+  constexpr int NW = (3 * BN * 4) / 256;       // 16-byte weight pieces per thread per step
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int r32 = lane & 31, half = lane >> 5;
+  const int arow = tid >> 1, khalf = tid & 1;
+
+  int m0, n0;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    n0 = (lid % tiles_n) * BN;
+    m0 = (lid / tiles_n) * BM;
+  }
+  const float* A = p.A;
+  float* out = p.out;
+  unsigned long long t_start = 0, t_loop = 0;
+  if (p.stamps) t_start = __builtin_amdgcn_s_memtime();
+
+  const int ntaps = p.ntaps, dil = p.tap_dil;
+  const int win = BM + (ntaps - 1) * dil;
+  unsigned char* const ldsA = reinterpret_cast<unsigned char*>(smem);            // [3][win][80 B]
+  unsigned char* const ldsW = ldsA + 3 * win * X6_ROWB;                          // [3][BN][80 B]
+
+  unsigned avalid = 0;
+#pragma unroll
+  for (int i = 0; i < NA2; ++i) {
+    const int r = arow + 128 * i;
+    const long ar = (long)m0 + p.tap_row0 + r;
+    bool ok = (r < win) && (ar >= 0) && (ar < p.a_rows);
+    if (ok && p.rowmask_in) ok = p.rowmask_in[ar] != 0;
+    avalid |= ok ? (1u << i) : 0u;
+  }
+
+  f32x4 pa[NA2][4];
+  u32x4 pw[NW];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const u32x4 zerou = {0u, 0u, 0u, 0u};
+
+  auto load_A = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < NA2; ++i) {
+      const long ar = (long)m0 + p.tap_row0 + arow + 128 * i;
+      const float* src = A + ar * p.lda + c0 + 16 * khalf;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) pa[i][v] = ((avalid >> i) & 1u) ? *reinterpret_cast<const f32x4*>(src + 4 * v) : zero4;
+    }
+  };
+  auto load_W = [&](int j, int c0) {
+    const int kb = j * p.Cin + c0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int idx = tid + 256 * i;
+      const int plane = idx / (BN * 4), rem = idx % (BN * 4);
+      const int n = n0 + (rem >> 2), c8 = rem & 3;
+      pw[i] = (n < p.n_rows_w)
+                  ? *reinterpret_cast<const u32x4*>(p.W3 + (long)plane * p.w3_plane + (long)n * p.ldw + kb + 8 * c8)
+                  : zerou;
+    }
+  };
+  auto store_A = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < NA2; ++i) {
+      const int r = arow + 128 * i;
+      if (r < win) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {          // two groups of 8 consecutive k
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = pa[i][2 * g + (e >> 2)][e & 3];
+          if (PRO == PRO_SNAKE) {
+            const float* al = p.pro_alpha + c0 + 16 * khalf + 8 * g;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float a = al[e];
+              const float sn = sinf(x[e] * a);
+              x[e] = x[e] + (1.0f / (a + 1e-9f)) * (sn * sn);
+            }
+          } else if (PRO == PRO_LRELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = x[e] > 0.f ? x[e] : x[e] * p.pro_slope;
+          }
+          u32x4 h, m, l;
+          split3x8(x, h, m, l);
+          unsigned char* dst = ldsA + r * X6_ROWB + (16 * khalf + 8 * g) * 2;
+          *reinterpret_cast<u32x4*>(dst) = h;
+          *reinterpret_cast<u32x4*>(dst + win * X6_ROWB) = m;
+          *reinterpret_cast<u32x4*>(dst + 2 * win * X6_ROWB) = l;
+        }
+      }
+    }
+  };
+  auto store_W = [&]() {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int idx = tid + 256 * i;
+      const int plane = idx / (BN * 4), rem = idx % (BN * 4);
+      *reinterpret_cast<u32x4*>(ldsW + (plane * BN + (rem >> 2)) * X6_ROWB + (rem & 3) * 16) = pw[i];
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+
+  const int nchunks = p.Cin >> 5;
+  const int nsteps = nchunks * ntaps;
+  load_A(0);
+  load_W(0, 0);
+  if (p.stamps) t_loop = __builtin_amdgcn_s_memtime();
+  int c = 0, j = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    __syncthreads();
+    if (j == 0) store_A(c * 32);
+    store_W();
+    __syncthreads();
+    int j2 = j + 1, c2 = c;
+    if (j2 == ntaps) { j2 = 0; c2 = c + 1; }
+    if (s + 1 < nsteps) {
+      if (j2 == 0) load_A(c2 * 32);
+      load_W(j2, c2 * 32);
+    }
+    const unsigned char* la = ldsA + (wm * WM + r32 + j * dil) * X6_ROWB + 16 * half;
+    const unsigned char* lw = ldsW + (wn * WN + r32) * X6_ROWB + 16 * half;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {            // two k-steps of 16 per 32-channel chunk
+      bf16x8 a[MT][3], b[NT][3];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          a[mt][pl] = *reinterpret_cast<const bf16x8*>(la + (pl * win + mt * 32) * X6_ROWB + 32 * ks);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          b[nt][pl] = *reinterpret_cast<const bf16x8*>(lw + (pl * BN + nt * 32) * X6_ROWB + 32 * ks);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          f32x16 t = acc[mt][nt];
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][2], b[nt][0], t, 0, 0, 0);   // smallest terms first
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][0], b[nt][2], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][1], b[nt][1], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][1], b[nt][0], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][0], b[nt][1], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][0], b[nt][0], t, 0, 0, 0);
+          acc[mt][nt] = t;
+        }
+    }
+    j = j2;
+    c = c2;
+  }
+  __syncthreads();
+  conv_epilogue<WM, WN, EPI>(p, out, acc, smem, m0, n0, wm, wn, t_start, t_loop);
+}
+
+namespace {
+
+template <int BM, int BN>
+size_t x6_lds_bytes(const ConvGemmArgs& a) {
+  const int win = BM + (a.ntaps - 1) * a.tap_dil;
+  return (size_t)3 * (win + BN) * X6_ROWB;
+}
+
+template <int BM, int BN, int WM, int WN, int PRO, int EPI>
+int x6_launch2(const ConvGemmArgs& a, hipStream_t st) {
+  static bool raised = false;
+  if (!raised) {
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    raised = true;
+  }
+  size_t lds = x6_lds_bytes<BM, BN>(a);
+  const size_t need = (size_t)4 * 32 * (WN + 4) * sizeof(float);
+  if (lds < need) lds = need;
+  const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
+  const bool prof = prof_on();
+  if (prof) prof_begin(st);
+  hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI>), dim3(tiles_m * tiles_n), dim3(256), lds, st, a, tiles_n);
+  if (prof) {
+    static const std::string name = std::string("conv_gemm_x6<") + std::to_string(BM) + "x" + std::to_string(BN) +
+                                    (PRO == PRO_SNAKE ? ",snake" : PRO == PRO_LRELU ? ",lrelu" : "") +
+                                    (EPI == 1 ? ",gelu" : EPI == 2 ? ",res" : EPI == 4 ? ",generic" : "") + ">";
+    const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M);
+    const double k = (double)(a.alg_k > 0 ? a.alg_k : a.ntaps * a.Cin);
+    const double bytes = 4.0 * (rows * a.Cin + (double)a.N * k + rows * a.N * (1 + (a.res1 ? 1 : 0) + (a.res2 ? 1 : 0)));
+    prof_end(st, name.c_str(), 2.0 * rows * a.N * k, bytes);
+  }
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int PRO>
+int x6_launch1(const ConvGemmArgs& a, hipStream_t st) {
+  const bool lean = !(a.N & 3) && !(a.ldo & 3) && (!a.res1 || !(a.ldr1 & 3)) && !a.res2 && !a.rowvec && !a.rowmask_out &&
+                    !a.accumulate && a.out_scale == 1.f;
+  if (lean && a.act == ACT_NONE)
+    return a.res1 ? x6_launch2<BM, BN, WM, WN, PRO, 2>(a, st) : x6_launch2<BM, BN, WM, WN, PRO, 0>(a, st);
+  if (lean && a.act == ACT_GELU && PRO == PRO_NONE && !a.res1) return x6_launch2<BM, BN, WM, WN, PRO_NONE, 1>(a, st);
+  return x6_launch2<BM, BN, WM, WN, PRO, 4>(a, st);
+}
+
+template <int BM, int BN, int WM, int WN>
+int x6_launch(const ConvGemmArgs& a, hipStream_t st) {
+  switch (a.pro) {
+    case PRO_NONE: return x6_launch1<BM, BN, WM, WN, PRO_NONE>(a, st);
+    case PRO_SNAKE: return x6_launch1<BM, BN, WM, WN, PRO_SNAKE>(a, st);
+    case PRO_LRELU: return x6_launch1<BM, BN, WM, WN, PRO_LRELU>(a, st);
+    default: return fail(JV_ERR_ARG, "conv_gemm: unknown prologue");
+  }
+}
+
+}  // namespace
+
+// Same contract as conv_gemm() (argument checks done there); requires a.W3.
+int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st) {
+  const int span = (a.ntaps - 1) * a.tap_dil;
+  struct Cand { int bm, bn; double eff; size_t lds; };
+  const Cand cands[3] = {{128, 128, 1.0, x6_lds_bytes<128, 128>(a)}, {64, 128, 0.95, x6_lds_bytes<64, 128>(a)},
+                         {64, 64, 0.88, x6_lds_bytes<64, 64>(a)}};
+  int best = -1;
+  double best_cost = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (cands[i].bm + span > 256) continue;
+    if (cands[i].lds > 80 * 1024 && i < 2) continue;
+    const long tiles = (long)cdiv(a.M, cands[i].bm) * cdiv(a.N, cands[i].bn);
+    const double cost = (double)cdivl(tiles, 256) * cands[i].bm * cands[i].bn / cands[i].eff;
+    if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+  }
+  if (const char* force = getenv("JV_TILE")) {
+    const int f = atoi(force);
+    if (f >= 0 && f <= 2 && cands[f].bm + span <= 256) best = f;
+  }
+  switch (best) {
+    case 0: return x6_launch<128, 128, 64, 64>(a, st);
+    case 1: return x6_launch<64, 128, 32, 64>(a, st);
+    case 2: return x6_launch<64, 64, 32, 32>(a, st);
+    default: return fail(JV_ERR_ARG, "conv_gemm_x6: no tile variant fits this tap span");
+  }
+}
+
+}  // namespace jv

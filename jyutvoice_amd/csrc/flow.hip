@@ -85,6 +85,7 @@ ConvGemmArgs base_args(const Geo& g, const float* A, int lda, const GemmW& w, fl
   a.A = A; a.lda = lda; a.a_rows = g.a_rows; a.M = (int)g.M;
   a.Cin = w.Cin; a.ntaps = w.ntaps; a.tap_row0 = 0; a.tap_dil = 1;
   a.W = w.w; a.ldw = w.ldw; a.n_rows_w = w.n_rows; a.N = w.N; a.bias = w.bias;
+  a.W3 = w.w3; a.w3_plane = (long)w.n_rows * w.ldw;
   a.out = out; a.ldo = ldo;
   a.alg_rows = (long)g.B2 * g.T;
   return a;

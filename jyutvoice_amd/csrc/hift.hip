@@ -115,6 +115,7 @@ ConvGemmArgs conv_args(const float* A, int lda, long a_rows, long M, const GemmW
   a.A = A; a.lda = lda; a.a_rows = a_rows; a.M = (int)M;
   a.Cin = w.Cin; a.ntaps = w.ntaps; a.tap_row0 = tap_row0; a.tap_dil = dil;
   a.W = w.w; a.ldw = w.ldw; a.n_rows_w = w.n_rows; a.N = w.N; a.bias = w.bias;
+  a.W3 = w.w3; a.w3_plane = (long)w.n_rows * w.ldw;
   a.out = out; a.ldo = ldo;
   a.rowmask_in = mask_in;
   return a;

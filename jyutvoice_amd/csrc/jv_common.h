@@ -56,6 +56,8 @@ struct ConvGemmArgs {
   int ntaps, tap_row0, tap_dil;
   // W: packed [n_rows_w][ldw], K-contiguous: column j*Cin + ci multiplies tap j, channel ci
   const float* W;
+  const unsigned short* W3;   // optional: the same matrix as three bf16 planes [3][n_rows_w][ldw] (bf16x6 path)
+  long w3_plane;              // elements between planes
   int ldw;
   int n_rows_w;    // rows of W that may be read (>= N, zero padded)
   int N;           // valid output columns
@@ -97,6 +99,7 @@ struct ConvGemmArgs {
 void conv_gemm_defaults(ConvGemmArgs& a);
 int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st);
 int conv_gemm_init();   // raises the dynamic-LDS limit of every instantiation
+int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st);   // bf16x6 main loop (conv_gemm_x6.hip); needs a.W3
 
 // ---- in-library kernel profiler (profile.hip): HIP events around the hot kernels, on the launch stream ----------
 bool prof_on();

@@ -43,6 +43,7 @@ struct Arena {
 // a packed weight matrix for conv_gemm: rows = output channels, K-contiguous, column j*Cin + ci
 struct GemmW {
   const float* w = nullptr;
+  const unsigned short* w3 = nullptr;   // three bf16 planes of w (split at load time), plane stride n_rows*ldw
   int ldw = 0, n_rows = 0, N = 0, Cin = 0, ntaps = 1;
   const float* bias = nullptr;
 };

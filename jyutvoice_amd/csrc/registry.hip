@@ -206,6 +206,20 @@ __global__ void tile_bias_kernel(const float* __restrict__ src, float* __restric
   if (i < n * reps) dst[i] = src[i % n];
 }
 
+// fp32 -> three bf16 planes (h, m, l) with x ~= h + m + l to 24 bits (conv_gemm_x6.hip)
+__global__ void split3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = src[i];
+  const __bf16 h = (__bf16)x;
+  const float r = x - (float)h;
+  const __bf16 m = (__bf16)r;
+  const __bf16 l = (__bf16)(r - (float)m);
+  dst[i] = __builtin_bit_cast(unsigned short, h);
+  dst[n + i] = __builtin_bit_cast(unsigned short, m);
+  dst[2 * n + i] = __builtin_bit_cast(unsigned short, l);
+}
+
 // w[r][:] = v[r][:] * (g[r] / ||v[r][:]||)
 __global__ __launch_bounds__(256) void fold_wn_kernel(const float* __restrict__ v, const float* __restrict__ g,
                                                       float* __restrict__ w, int cols) {
@@ -221,6 +235,17 @@ __global__ __launch_bounds__(256) void fold_wn_kernel(const float* __restrict__ 
   const float scale = g[r] / sqrtf(tot);
   for (int i = threadIdx.x; i < cols; i += 256) w[(long)r * cols + i] = vr[i] * scale;
 }
+
+}  // namespace
+
+// test hook: split an arbitrary [n] fp32 matrix into bf16x6 planes (used by jv_op_conv_gemm)
+int split3_planes(const float* src, unsigned short* dst, long n, hipStream_t st) {
+  hipLaunchKernelGGL(split3_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, src, dst, n);
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+namespace {
 
 struct Packer {
   Context& c;
@@ -254,6 +279,15 @@ struct Packer {
     hipLaunchKernelGGL(fold_wn_kernel, dim3(rows), dim3(256), 0, st, v->dev, g->dev, w, cols);
     return w;
   }
+  // attach the bf16x6 planes to a finished GemmW
+  void split(GemmW& g) {
+    if (!g.w || rc != JV_OK) return;
+    const long n = (long)g.n_rows * g.ldw;
+    float* d = alloc((size_t)(3 * n + 1) / 2 + 8);
+    if (!d) return;
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, g.w, reinterpret_cast<unsigned short*>(d), n);
+    g.w3 = reinterpret_cast<const unsigned short*>(d);
+  }
   // conv weight [cout][cin][k] (device, plain) -> GemmW with cin padded to cinp
   GemmW conv(const float* w, int cout, int cin, int k, int cinp, const float* bias) {
     GemmW g;
@@ -265,6 +299,7 @@ struct Packer {
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, w, d, cout, cin, k, cinp, ldw,
                        0);
     g.w = d; g.ldw = ldw; g.n_rows = cout; g.N = cout; g.Cin = cinp; g.ntaps = k; g.bias = bias;
+    split(g);
     return g;
   }
   GemmW conv_named(const std::string& p, int cout, int cin, int k, int cinp = 0) {
@@ -279,6 +314,7 @@ struct Packer {
     GemmW g;
     g.w = ptr(wname); g.ldw = k; g.n_rows = n; g.N = n; g.Cin = k; g.ntaps = 1;
     g.bias = bname.empty() ? nullptr : ptr(bname);
+    split(g);
     return g;
   }
   // vertical concatenation of [n_i][k] matrices (+ optional biases)
@@ -301,6 +337,7 @@ struct Packer {
       }
     }
     g.w = d; g.ldw = k; g.n_rows = parts * n_each; g.N = parts * n_each; g.Cin = k; g.ntaps = 1; g.bias = b;
+    split(g);
     return g;
   }
   GemmW convT_wn(const std::string& p, int cin, int cout, int k, int s) {
@@ -316,6 +353,7 @@ struct Packer {
                        (k - s) / 2);
     hipLaunchKernelGGL(tile_bias_kernel, dim3(cdiv(s * cout, 256)), dim3(256), 0, st, bias, b, cout, s);
     g.w = d; g.ldw = 3 * cin; g.n_rows = s * cout; g.N = s * cout; g.Cin = cin; g.ntaps = 3; g.bias = b;
+    split(g);
     return g;
   }
   LnW ln(const std::string& p, const char* gname, const char* bname) { return LnW{ptr(p + gname), ptr(p + bname)}; }

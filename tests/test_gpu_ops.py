@@ -146,3 +146,40 @@ def test_layernorm(dev, C, eps):
     out = op_layernorm(x.to(dev), w.to(dev), b.to(dev), eps)
     want = F.layer_norm(x.double(), (C,), w.double(), b.double(), eps)
     assert float((out.double().cpu() - want).abs().max()) < 1e-5
+
+
+@pytest.fixture
+def x6(monkeypatch):
+    """route jv_op_conv_gemm through the bf16x6 main loop (three bf16 planes per operand, six MFMA products)"""
+    monkeypatch.setenv("JV_OP_X6", "1")
+    monkeypatch.delenv("JV_NO_X6", raising=False)
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 256, 1536), (19, 1024, 256), (1000, 512, 80), (4100, 256, 256)])
+def test_x6_linear_fp32_accuracy(dev, x6, M, K, N):
+    """bf16x6 must be as accurate as the fp32-MFMA kernel: same bound against fp64"""
+    from jyutvoice_amd.engine import op_conv_gemm
+    g = torch.Generator().manual_seed(M + K + N)
+    A = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))      # rows of very different scale
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    out = op_conv_gemm(A.to(dev), W.to(dev), b.to(dev))
+    want = A.double() @ W.double().T + b.double()
+    assert rel_err(out, want) < 2e-6
+    row_scale = A.double().abs().max(dim=1, keepdim=True).values
+    assert float(((out.double().cpu() - want).abs() / row_scale).max()) < 2e-6
+
+
+@pytest.mark.parametrize("k,dil,C", [(11, 5, 64), (7, 3, 128), (3, 1, 256)])
+def test_x6_dilated_conv_snake_residual(dev, x6, k, dil, C):
+    test_dilated_conv_snake_residual(dev, k, dil, C)
+
+
+def test_x6_causal_conv_ln_mish_mask(dev, x6):
+    test_causal_conv_ln_mish_mask(dev)
+
+
+def test_x6_gelu_and_generic_epilogues(dev, x6):
+    test_activations(dev, "gelu")
+    test_activations(dev, "elu")
+    test_lrelu_prologue(dev)
