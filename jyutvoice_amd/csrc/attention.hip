@@ -36,7 +36,8 @@ __global__ __launch_bounds__(64 * NW) void attn64_kernel(const AttnArgs p) {
   const long rowbase = (long)p.G + (long)b * p.S;
   const bool active = q0 < p.L;
 
-  // Q fragment: this lane's query row, dims [32*half, 32*half+32), pre-scaled by 1/sqrt(64) (exact)
+  // Q fragment: this lane's query row, dims [32*half, 32*half+32), pre-scaled by log2(e)/sqrt(64): scores come out in
+  // base-2 units so the softmax needs one v_exp_f32 per element (exp(x) == exp2(x log2 e))
   float q[32];
   {
     const int qi = q0 + r32;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(64 * NW) void attn64_kernel(const AttnArgs p) {
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
       if (qi < p.L) t = *reinterpret_cast<const f32x4*>(src + 4 * i);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) q[4 * i + e] = t[e] * 0.125f;
+      for (int e = 0; e < 4; ++e) q[4 * i + e] = t[e] * (0.125f * 1.44269504088896340736f);
     }
   }
 
@@ -112,11 +113,11 @@ __global__ __launch_bounds__(64 * NW) void attn64_kernel(const AttnArgs p) {
     }
     mt = fmaxf(mt, __shfl_xor(mt, 32));
     const float m_new = fmaxf(m_run, mt);
-    const float alpha = expf(m_run - m_new);
+    const float alpha = exp2f(m_run - m_new);
     float lt = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      s[e] = expf(s[e] - m_new);
+      s[e] = exp2f(s[e] - m_new);
       lt += s[e];
     }
     lt += __shfl_xor(lt, 32);

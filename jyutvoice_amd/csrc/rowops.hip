@@ -12,6 +12,44 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- LayerNorm over the channel axis of a row buffer (optionally of x + add) -------------------
 // One wave per row; two-pass (mean, then centred sum of squares) entirely in registers for C <= 1024.
+// C == 256 fast path: one wave handles 4 rows at once (4 independent 16-byte loads per lane in flight), the rest as below
+__global__ __launch_bounds__(256) void layernorm256_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                           const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                                           long rows) {
+  const int lane = threadIdx.x & 63;
+  const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+  f32x4 v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    v[r] = (row0 + r < rows) ? *reinterpret_cast<const f32x4*>(x + (row0 + r) * 256 + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * lane);
+  const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 4 * lane);
+  float sum[4], sq[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sum[r] = (v[r][0] + v[r][1]) + (v[r][2] + v[r][3]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sum[r] += __shfl_xor(sum[r], o);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const f32x4 d = v[r] - sum[r] * (1.f / 256.f);
+    sq[r] = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sq[r] += __shfl_xor(sq[r], o);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (row0 + r < rows) {
+      const float mean = sum[r] * (1.f / 256.f);
+      const float rstd = 1.0f / sqrtf(sq[r] * (1.f / 256.f) + eps);
+      *reinterpret_cast<f32x4*>(out + (row0 + r) * 256 + 4 * lane) = (v[r] - mean) * rstd * gg + bb;
+    }
+  }
+}
+
 template <int VPL>   // f32x4 per lane
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                              float* __restrict__ out, const float* __restrict__ g,
@@ -69,7 +107,9 @@ int layernorm_rows(const float* x, const float* add, float* out, const float* g,
   if (rows <= 0) return JV_OK;
   if (C & 3 || C > 1024) return fail(JV_ERR_ARG, "layernorm_rows: C must be a multiple of 4, <= 1024");
   const dim3 grid((unsigned)cdivl(rows, 4));
-  if (C <= 256)
+  if (C == 256 && !add && !rowmask_out && !relu)
+    hipLaunchKernelGGL(layernorm256_kernel, dim3((unsigned)cdivl(rows, 16)), dim3(256), 0, st, x, out, g, b, eps, rows);
+  else if (C <= 256)
     hipLaunchKernelGGL((layernorm_rows_kernel<1>), grid, dim3(256), 0, st, x, add, out, g, b, eps, rows, C, rowmask_out, relu);
   else if (C <= 768)
     hipLaunchKernelGGL((layernorm_rows_kernel<3>), grid, dim3(256), 0, st, x, add, out, g, b, eps, rows, C, rowmask_out, relu);
