@@ -43,6 +43,43 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
     else
       for (int e = 0; e < 4; ++e) bb[e] = (n + e < p.N) ? p.bias[n + e] : 0.f;
   }
+  if constexpr (EPI != 4) {
+    if (!(p.ablate & 256)) {
+      // lean path, straight from the accumulators in MFMA layout: register e of a 32x32 tile is row (e&3)+8(e>>2)+4*half,
+      // column lane&31, so each half-wave stores 128 contiguous bytes per instruction -- no LDS round trip, no barrier.
+      constexpr bool E_GELU = (EPI & 1) != 0, E_RES = (EPI & 2) != 0;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int nn = n0 + wn * WN + nt * 32 + r32;
+          const bool nok = nn < p.N;
+          const float bn = (p.bias && nok) ? p.bias[nn] : 0.f;
+          const int mb = m0 + wm * WM + mt * 32 + 4 * half;
+          float r[16];
+          if constexpr (E_RES) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int m = mb + (e & 3) + 8 * (e >> 2);
+              r[e] = (nok && m < p.M) ? p.res1[(long)m * p.ldr1 + nn] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = mb + (e & 3) + 8 * (e >> 2);
+            float t = acc[mt][nt][e] + bn;
+            if constexpr (E_GELU) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752440f));
+            if constexpr (E_RES) t += r[e];
+            if (nok && m < p.M && !(p.ablate & 64)) out[(long)m * p.ldo + nn] = t;
+          }
+        }
+      if (p.stamps && tid == 0) {
+        unsigned long long* d = p.stamps + (size_t)blockIdx.x * 4;
+        d[0] = t_start; d[1] = t_loop; d[2] = t_epi; d[3] = __builtin_amdgcn_s_memtime();
+      }
+      return;
+    }
+  }
   auto pass = [&](auto mt_tag) {
     constexpr int mt = decltype(mt_tag)::value;
     if (mt > 0) __syncthreads();

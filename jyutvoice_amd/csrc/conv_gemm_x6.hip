@@ -15,7 +15,10 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include <string>
+#include <vector>
 
 #include "conv_gemm_epilogue.h"
 #include "jv_common.h"
@@ -235,6 +238,26 @@ int x6_launch2(const ConvGemmArgs& a, hipStream_t st) {
   const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
   const bool prof = prof_on();
   if (prof) prof_begin(st);
+  if (getenv("JV_STAMPS")) {   // diagnostic only: synchronous, prints phase shares of this launch
+    static unsigned long long* dbuf = nullptr;
+    const unsigned nwg = tiles_m * tiles_n;
+    if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 4 * 65536);
+    ConvGemmArgs b = a;
+    b.stamps = nwg <= 65536 ? dbuf : nullptr;
+    hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI>), dim3(nwg), dim3(256), lds, st, b, tiles_n);
+    (void)hipStreamSynchronize(st);
+    if (b.stamps) {
+      std::vector<unsigned long long> h((size_t)nwg * 4);
+      (void)hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
+      double pro = 0, loop = 0, epi = 0;
+      for (unsigned i = 0; i < nwg; ++i) {
+        pro += (double)(h[4 * i + 1] - h[4 * i]); loop += (double)(h[4 * i + 2] - h[4 * i + 1]); epi += (double)(h[4 * i + 3] - h[4 * i + 2]);
+      }
+      fprintf(stderr, "[stamps x6] %dx%d grid %u: prologue %.0f  loop %.0f  epilogue %.0f cycles avg per workgroup\n", BM, BN, nwg,
+              pro / nwg, loop / nwg, epi / nwg);
+    }
+    return JV_OK;
+  }
   hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI>), dim3(tiles_m * tiles_n), dim3(256), lds, st, a, tiles_n);
   if (prof) {
     static const std::string name = std::string("conv_gemm_x6<") + std::to_string(BM) + "x" + std::to_string(BN) +
