@@ -11,6 +11,7 @@
 // one lane^32 exchange per reduction.  K/V tiles of 32 keys are shared by the workgroup's waves through
 // LDS (row stride 68 floats: conflict-free ds_read_b128) and register-prefetched one tile ahead.
 #include <math.h>
+#include <stdlib.h>
 
 #include "jv_common.h"
 
@@ -148,23 +149,221 @@ __global__ __launch_bounds__(64 * NW) void attn64_kernel(const AttnArgs p) {
   }
 }
 
+// ---- bf16x6 variant: same algorithm, contractions as six bf16 MFMA products of 3-plane splits (conv_gemm_x6.hip) -----
+// K is split while it is staged ([3][32 keys][64 d], 144-byte rows); V is split AND transposed to [3][64 d][32 keys]
+// (80-byte rows) so that the PV product's A operand is 8 consecutive keys of one d; the key order inside a tile is the
+// one the S^T accumulator already has (register e of lane-half h holds key (e&3)+8(e>>2)+4h), i.e. position p in the V^T
+// row holds key swap_bits23(p): P goes from the softmax to the MFMA with three conversions and no data movement.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int AK_ROWB = 144, AV_ROWB = 80;
+
+// x -> (h, m, l) bf16 with x ~= h + m + l to 24 bits; a macro because vector elements cannot bind to references
+#define JV_SPLIT3(x, H, M, L)                 \
+  do {                                        \
+    const float _x = (x);                     \
+    const __bf16 _h = (__bf16)_x;             \
+    const float _r = _x - (float)_h;          \
+    const __bf16 _m = (__bf16)_r;             \
+    (H) = _h;                                 \
+    (M) = _m;                                 \
+    (L) = (__bf16)(_r - (float)_m);           \
+  } while (0)
+
+__device__ __forceinline__ f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+  return c;
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn64_x6_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char ldsK[3 * 32 * AK_ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char ldsV[3 * 64 * AV_ROWB];
+  constexpr int NT = 64 * NW;
+  constexpr int NKL = (32 * 16) / NT;   // f32x4 pieces of K per thread per tile
+  constexpr int KPT = 32 / NW;          // keys of V per thread per tile (one d column each)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 32 * NW + wave * 32;
+  const int len = p.lens ? min(p.lens[b], p.L) : p.L;
+  const long rowbase = (long)p.G + (long)b * p.S;
+  const bool active = q0 < p.L;
+
+  // Q planes: lane (query, half) holds d = 16 s + 8 half + j for k-step s, pre-scaled by log2(e)/8
+  bf16x8 q[4][3];
+  {
+    const int qi = q0 + r32;
+    const float* src = p.qkv + (rowbase + qi) * p.ld + h * 64 + 8 * half;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+      if (qi < p.L) {
+        t0 = *reinterpret_cast<const f32x4*>(src + 16 * s);
+        t1 = *reinterpret_cast<const f32x4*>(src + 16 * s + 4);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = (e < 4 ? t0[e & 3] : t1[e & 3]) * (0.125f * 1.44269504088896340736f);
+        JV_SPLIT3(x, q[s][0][e], q[s][1][e], q[s][2][e]);
+      }
+    }
+  }
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  f32x4 pk[NKL];
+  float pv[KPT];
+  const int vd = tid & 63, vkg = tid >> 6;
+  auto prefetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) {
+      const int idx = tid + i * NT;
+      const int key = idx >> 4, c4 = idx & 15;
+      pk[i] = (k0 + key < len) ? *reinterpret_cast<const f32x4*>(p.qkv + (rowbase + k0 + key) * p.ld + p.k_off + h * 64 + 4 * c4)
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int key = vkg * KPT + i;
+      pv[i] = (k0 + key < len) ? p.qkv[(rowbase + k0 + key) * p.ld + p.v_off + h * 64 + vd] : 0.f;
+    }
+  };
+
+  const int nkt = (len + 31) >> 5;
+  if (nkt > 0) prefetch(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int k0 = kt * 32;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) {
+      const int idx = tid + i * NT;
+      const int key = idx >> 4, c4 = idx & 15;
+      bf16x4 hh, mm, ll;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) JV_SPLIT3(pk[i][e], hh[e], mm[e], ll[e]);
+      unsigned char* dst = ldsK + key * AK_ROWB + c4 * 8;
+      *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, hh);
+      *reinterpret_cast<u32x2*>(dst + 32 * AK_ROWB) = __builtin_bit_cast(u32x2, mm);
+      *reinterpret_cast<u32x2*>(dst + 64 * AK_ROWB) = __builtin_bit_cast(u32x2, ll);
+    }
+#pragma unroll
+    for (int g = 0; g < KPT / 4; ++g) {         // 4 consecutive keys stay consecutive under the bit swap
+      const int key = vkg * KPT + 4 * g;
+      const int pos = (key & 0x13) | ((key & 4) << 1) | ((key & 8) >> 1);
+      bf16x4 hh, mm, ll;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) JV_SPLIT3(pv[4 * g + e], hh[e], mm[e], ll[e]);
+      unsigned char* dst = ldsV + vd * AV_ROWB + pos * 2;
+      *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, hh);
+      *reinterpret_cast<u32x2*>(dst + 64 * AV_ROWB) = __builtin_bit_cast(u32x2, mm);
+      *reinterpret_cast<u32x2*>(dst + 128 * AV_ROWB) = __builtin_bit_cast(u32x2, ll);
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) prefetch(k0 + 32);
+    if (!active) continue;
+
+    // S^T[key][query] = sum_d K[key][d] * Q[query][d]
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+    const unsigned char* kr = ldsK + r32 * AK_ROWB + 16 * half;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      bf16x8 a[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(kr + pl * 32 * AK_ROWB + 32 * st);
+      s = mfma6(a, q[st], s);
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+      s[e] = key < len ? s[e] : -INFINITY;
+      mt = fmaxf(mt, s[e]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = exp2f(m_run - m_new);
+    float lt = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      s[e] = exp2f(s[e] - m_new);
+      lt += s[e];
+    }
+    lt += __shfl_xor(lt, 32);
+    l_run = l_run * alpha + lt;
+    m_run = m_new;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+    // O^T[d][query] += sum_key V[key][d] * P[query][key]
+    const unsigned char* vr = ldsV + r32 * AV_ROWB + 16 * half;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      bf16x8 pb[3];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) JV_SPLIT3(s[8 * st + e], pb[0][e], pb[1][e], pb[2][e]);
+      bf16x8 a[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(vr + pl * 64 * AV_ROWB + 32 * st);
+      o0 = mfma6(a, pb, o0);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(vr + (pl * 64 + 32) * AV_ROWB + 32 * st);
+      o1 = mfma6(a, pb, o1);
+    }
+  }
+
+  const int qi = q0 + r32;
+  if (active && qi < p.L) {
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    float* dst = p.out + (rowbase + qi) * p.ldo + h * 64 + 4 * half;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 a = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+      const f32x4 c = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+      *reinterpret_cast<f32x4*>(dst + 8 * g) = a;
+      *reinterpret_cast<f32x4*>(dst + 32 + 8 * g) = c;
+    }
+  }
+}
+
 int attention64(const AttnArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.L <= 0) return JV_OK;
   if ((a.ld & 3) || (a.ldo & 3) || (a.k_off & 3) || (a.v_off & 3))
     return fail(JV_ERR_ARG, "attention64: strides/offsets must be multiples of 4 floats");
   // 64-query workgroups waste least on T = 300 (5 x 64); 128-query ones halve K/V staging at T = 512
-  const int waste2 = round_up(a.L, 64) - a.L, waste4 = round_up(a.L, 128) - a.L;
+  static const bool fp32_path = getenv("JV_ATTN_FP32") != nullptr;
+  int waste2 = round_up(a.L, 64) - a.L, waste4 = round_up(a.L, 128) - a.L;
+  // bf16x6: staging (split + V transpose) is per thread, so the 4-wave workgroup is ~1.4x faster per query row
+  // (measured 110 vs 76 TFLOP/s): prefer it unless its padding costs more than that
+  if (!fp32_path && round_up(a.L, 128) * 10 <= round_up(a.L, 64) * 13) waste4 = -1;
   const bool prof = prof_on();
   if (prof) prof_begin(st);
   if (waste4 <= waste2) {
-    hipLaunchKernelGGL((attn64_kernel<4>), dim3(cdiv(a.L, 128), a.H, a.B), dim3(256), 0, st, a);
+    if (fp32_path) hipLaunchKernelGGL((attn64_kernel<4>), dim3(cdiv(a.L, 128), a.H, a.B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn64_x6_kernel<4>), dim3(cdiv(a.L, 128), a.H, a.B), dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL((attn64_kernel<2>), dim3(cdiv(a.L, 64), a.H, a.B), dim3(128), 0, st, a);
+    if (fp32_path) hipLaunchKernelGGL((attn64_kernel<2>), dim3(cdiv(a.L, 64), a.H, a.B), dim3(128), 0, st, a);
+    else hipLaunchKernelGGL((attn64_x6_kernel<2>), dim3(cdiv(a.L, 64), a.H, a.B), dim3(128), 0, st, a);
   }
   if (prof) {
     // algorithmic (full-length) figure of SURVEY.md 8(d): QK^T + PV = 4*L*L*64 per head; q,k,v,o once
     const double bh = (double)a.B * a.H;
-    prof_end(st, waste4 <= waste2 ? "attn64<4 waves>" : "attn64<2 waves>", 4.0 * bh * a.L * a.L * 64.0, 4.0 * bh * a.L * 64.0 * 4.0);
+    prof_end(st, fp32_path ? (waste4 <= waste2 ? "attn64<4 waves>" : "attn64<2 waves>")
+                           : (waste4 <= waste2 ? "attn64_x6<4 waves>" : "attn64_x6<2 waves>"),
+             4.0 * bh * a.L * a.L * 64.0, 4.0 * bh * a.L * 64.0 * 4.0);
   }
   JV_HIP(hipGetLastError());
   return JV_OK;
