@@ -46,13 +46,15 @@ __device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& h, u32x4& m
   l = __builtin_bit_cast(u32x4, ll);
 }
 
-template <int BM, int BN, int WM, int WN, int PRO, int EPI>
-__global__ __launch_bounds__(256) void conv_gemm_x6_kernel(const ConvGemmArgs p, const int tiles_n) {
+// The 64x64 plain variants are held to 96 registers so five workgroups fit a CU: the N = 256 GEMMs of the estimator
+// make 1220 such tiles, which then all run in one resident wave (1280 slots) instead of 1024 + a 20 % tail.
+// NA2: window rows staged per thread (rows tid>>1 + 128 i): 1 when the A window fits 128 rows, else 2
+template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2>
+__global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EPI != 4) ? 5 : 2) void conv_gemm_x6_kernel(const ConvGemmArgs p, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-  constexpr int NA2 = 2;                       // window rows handled per thread: tid>>1 + 128*i
   constexpr int NW = (3 * BN * 4) / 256;       // 16-byte weight pieces per thread per step
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -224,11 +226,11 @@ size_t x6_lds_bytes(const ConvGemmArgs& a) {
   return (size_t)3 * (win + BN) * X6_ROWB;
 }
 
-template <int BM, int BN, int WM, int WN, int PRO, int EPI>
-int x6_launch2(const ConvGemmArgs& a, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2>
+int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
   static bool raised = false;
   if (!raised) {
-    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI>),
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     raised = true;
   }
@@ -244,7 +246,7 @@ int x6_launch2(const ConvGemmArgs& a, hipStream_t st) {
     if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 4 * 65536);
     ConvGemmArgs b = a;
     b.stamps = nwg <= 65536 ? dbuf : nullptr;
-    hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI>), dim3(nwg), dim3(256), lds, st, b, tiles_n);
+    hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2>), dim3(nwg), dim3(256), lds, st, b, tiles_n);
     (void)hipStreamSynchronize(st);
     if (b.stamps) {
       std::vector<unsigned long long> h((size_t)nwg * 4);
@@ -258,7 +260,7 @@ int x6_launch2(const ConvGemmArgs& a, hipStream_t st) {
     }
     return JV_OK;
   }
-  hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI>), dim3(tiles_m * tiles_n), dim3(256), lds, st, a, tiles_n);
+  hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2>), dim3(tiles_m * tiles_n), dim3(256), lds, st, a, tiles_n);
   if (prof) {
     static const std::string name = std::string("conv_gemm_x6<") + std::to_string(BM) + "x" + std::to_string(BN) +
                                     (PRO == PRO_SNAKE ? ",snake" : PRO == PRO_LRELU ? ",lrelu" : "") +
@@ -270,6 +272,16 @@ int x6_launch2(const ConvGemmArgs& a, hipStream_t st) {
   }
   JV_HIP(hipGetLastError());
   return JV_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int PRO, int EPI>
+int x6_launch2(const ConvGemmArgs& a, hipStream_t st) {
+  const int win = BM + (a.ntaps - 1) * a.tap_dil;
+  if constexpr (BM == 128) {
+    if (win > 128) return x6_launch3<BM, BN, WM, WN, PRO, EPI, 2>(a, st);
+  }
+  if (win > 128) return fail(JV_ERR_ARG, "conv_gemm_x6: window too tall for this tile variant");
+  return x6_launch3<BM, BN, WM, WN, PRO, EPI, 1>(a, st);
 }
 
 template <int BM, int BN, int WM, int WN, int PRO>
@@ -304,7 +316,7 @@ int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st) {
   int best = -1;
   double best_cost = 0;
   for (int i = 0; i < 3; ++i) {
-    if (cands[i].bm + span > 256) continue;
+    if (cands[i].bm + span > (i == 0 ? 256 : 128)) continue;
     if (cands[i].lds > 80 * 1024 && i < 2) continue;
     const long tiles = (long)cdiv(a.M, cands[i].bm) * cdiv(a.N, cands[i].bn);
     const double cost = (double)cdivl(tiles, 256) * cands[i].bm * cands[i].bn / cands[i].eff;
@@ -312,7 +324,7 @@ int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st) {
   }
   if (const char* force = getenv("JV_TILE")) {
     const int f = atoi(force);
-    if (f >= 0 && f <= 2 && cands[f].bm + span <= 256) best = f;
+    if (f >= 0 && f <= 2 && cands[f].bm + span <= (f == 0 ? 256 : 128)) best = f;
   }
   switch (best) {
     case 0: return x6_launch<128, 128, 64, 64>(a, st);
