@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0
 
 def kernel_peak(name: str):
     """(peak TFLOP/s of algorithmic fp32 work, description) for a profiled kernel family"""
-    if name.startswith("conv_gemm_x6"):
+    if name.startswith("conv_gemm_x6") or name.startswith("attn64_x6"):
         # bf16x6: every fp32-accurate multiply-add costs six bf16 MFMA products, so the ceiling for ALGORITHMIC flops is
         # the dense bf16 MFMA peak / 6
         return BF16_MFMA_PEAK_TFLOPS / 6.0, ("fp32 operands split into 3 bf16 planes, 6 x v_mfma_f32_32x32x16_bf16 per product, "
