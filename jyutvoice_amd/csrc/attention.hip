@@ -31,8 +31,19 @@ __global__ __launch_bounds__(64 * NW) void attn64_kernel(const AttnArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, half = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 32 * NW + wave * 32;
+  // flat grid, remapped so that each XCD gets a contiguous run of (b, h, q-tile) triples with the q-tile fastest: the
+  // q-tiles of one (b, h) then share that head's K/V in one L2 (round 1: FETCH_SIZE was 2.3x the algorithmic bytes)
+  int b, h, qt;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int nqt = (p.L + 32 * NW - 1) / (32 * NW);
+    qt = lid % nqt;
+    h = (lid / nqt) % p.H;
+    b = lid / (nqt * p.H);
+  }
+  const int q0 = qt * 32 * NW + wave * 32;
   const int len = p.lens ? min(p.lens[b], p.L) : p.L;
   const long rowbase = (long)p.G + (long)b * p.S;
   const bool active = q0 < p.L;
@@ -193,8 +204,19 @@ __global__ __launch_bounds__(64 * NW) void attn64_x6_kernel(const AttnArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, half = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 32 * NW + wave * 32;
+  // flat grid, remapped so that each XCD gets a contiguous run of (b, h, q-tile) triples with the q-tile fastest: the
+  // q-tiles of one (b, h) then share that head's K/V in one L2 (round 1: FETCH_SIZE was 2.3x the algorithmic bytes)
+  int b, h, qt;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int nqt = (p.L + 32 * NW - 1) / (32 * NW);
+    qt = lid % nqt;
+    h = (lid / nqt) % p.H;
+    b = lid / (nqt * p.H);
+  }
+  const int q0 = qt * 32 * NW + wave * 32;
   const int len = p.lens ? min(p.lens[b], p.L) : p.L;
   const long rowbase = (long)p.G + (long)b * p.S;
   const bool active = q0 < p.L;
@@ -352,11 +374,11 @@ int attention64(const AttnArgs& a, hipStream_t st) {
   const bool prof = prof_on();
   if (prof) prof_begin(st);
   if (waste4 <= waste2) {
-    if (fp32_path) hipLaunchKernelGGL((attn64_kernel<4>), dim3(cdiv(a.L, 128), a.H, a.B), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn64_x6_kernel<4>), dim3(cdiv(a.L, 128), a.H, a.B), dim3(256), 0, st, a);
+    if (fp32_path) hipLaunchKernelGGL((attn64_kernel<4>), dim3(cdiv(a.L, 128) * a.H * a.B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn64_x6_kernel<4>), dim3(cdiv(a.L, 128) * a.H * a.B), dim3(256), 0, st, a);
   } else {
-    if (fp32_path) hipLaunchKernelGGL((attn64_kernel<2>), dim3(cdiv(a.L, 64), a.H, a.B), dim3(128), 0, st, a);
-    else hipLaunchKernelGGL((attn64_x6_kernel<2>), dim3(cdiv(a.L, 64), a.H, a.B), dim3(128), 0, st, a);
+    if (fp32_path) hipLaunchKernelGGL((attn64_kernel<2>), dim3(cdiv(a.L, 64) * a.H * a.B), dim3(128), 0, st, a);
+    else hipLaunchKernelGGL((attn64_x6_kernel<2>), dim3(cdiv(a.L, 64) * a.H * a.B), dim3(128), 0, st, a);
   }
   if (prof) {
     // algorithmic (full-length) figure of SURVEY.md 8(d): QK^T + PV = 4*L*L*64 per head; q,k,v,o once

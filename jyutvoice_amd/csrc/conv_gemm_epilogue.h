@@ -70,7 +70,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
             float t = acc[mt][nt][e] + bn;
             if constexpr (E_GELU) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752440f));
             if constexpr (E_RES) t += r[e];
-            if (nok && m < p.M && !(p.ablate & 64)) out[(long)m * p.ldo + nn] = t;
+            if (nok && m < p.M && !(p.ablate & 64)) out[(long)m * p.ldo + nn] = t;   // (non-temporal stores: no gain, A/B'd)
           }
         }
       if (p.stamps && tid == 0) {
