@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the conv_gemm / attention kernels on the estimator's shapes at C3 (M = 19.3K rows).
-    JV_TILE=0|1|2 python tools_gemm_bench.py      (tuning aid; prints TFLOP/s per shape)"""
+    JV_TILE=0|1|2 python tools/gemm_bench.py      (tuning aid; prints TFLOP/s per shape)"""
 import math
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jyutvoice_amd.engine import op_attention, op_conv_gemm  # noqa: E402
 
 dev = torch.device("cuda:0")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe for the GPU box (run through gpurun from the repo root):
-#   bash tools_profile.sh <tag>
+#   bash tools/profile.sh <tag>
 # 1. rocprofv3 --kernel-trace --stats of the default bench (per-kernel time)
 # 2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE) on a 1-step run, as MI355X_MICROARCH.md prescribes
 set -e
@@ -15,7 +15,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROO
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $OUT/pmc_write.json 2> $OUT/pmc_write.err || { tail -20 $OUT/pmc_write.err; exit 1; }
 echo "write done"
-python3 $ROOT/tools_profile_summary.py $OUT > $OUT/SUMMARY.md
+python3 $ROOT/tools/profile_summary.py $OUT > $OUT/SUMMARY.md
 cat $OUT/SUMMARY.md
 # keep only the small files (the raw per-dispatch CSVs are tens of MB)
 find $OUT -name "*kernel_trace.csv" -size +20M -delete || true
