@@ -67,6 +67,11 @@ int jv_finalize(jv_context* ctx, int model, void* stream);
  * out may alias x (the TRT seam writes its result into x). */
 int jv_flow_estimator_step(jv_context* ctx, const float* x, const int32_t* lens, const float* mu, const float* t,
                            const float* spks, const float* cond, int B2, int T, float* out, void* stream);
+/* jv_flow_set_streaming: the `streaming=True` mode of CausalConditionalDecoder.forward (decoder.py:951-954, 976-979,
+ * 999-1002 -> utils/mask.py:91-126,192-198): chunk-causal attention with static_chunk_size = chunk_frames (50 in
+ * configs/base.yaml:98) and all left chunks; 0 restores full attention.  Applies to the following estimator / solver
+ * calls on this context. */
+int jv_flow_set_streaming(jv_context* ctx, int chunk_frames);
 /* jv_cfm_solve: CausalConditionalCFM.forward + ConditionalCFM.solve_euler (flow_matching.py:356-401, 215-265):
  * fixed noise prefix * temperature, cosine schedule, n_timesteps Euler steps with CFG rate 0.7.
  * mu, cond, mel: [B,80,T]; spks: [B,80]; lens: [B] int32 or NULL.  t_span_host: optional n_timesteps+1 host floats

@@ -167,6 +167,13 @@ int jv_flow_estimator_step(jv_context* ctx, const float* x, const int32_t* lens,
   return jv::flow_estimator(ctx->c, x, lens, mu, t, spks, cond, B2, T, out, static_cast<hipStream_t>(stream));
 }
 
+int jv_flow_set_streaming(jv_context* ctx, int chunk_frames) {
+  if (!ctx) return jv::fail(JV_ERR_ARG, "null context");
+  if (chunk_frames < 0) return jv::fail(JV_ERR_ARG, "jv_flow_set_streaming: chunk must be >= 0");
+  ctx->c.attn_chunk = chunk_frames;
+  return JV_OK;
+}
+
 int jv_cfm_solve(jv_context* ctx, const float* mu, const int32_t* lens, const float* spks, const float* cond, int B, int T,
                  int n_timesteps, float temperature, const float* t_span_host, float* mel, void* stream) {
   CTX_GUARD(ctx);
@@ -211,7 +218,7 @@ int jv_op_conv_gemm(const float* A, int64_t a_rows, int M, int Cin, int ntaps, i
 int jv_op_attention(const float* qkv, const int32_t* lens, int B, int G, int S, int L, float* out, void* stream) {
   jv::AttnArgs at;
   at.qkv = qkv; at.ld = 1536; at.k_off = 512; at.v_off = 1024; at.out = out; at.ldo = 512;
-  at.B = B; at.H = 8; at.G = G; at.S = S; at.L = L; at.lens = lens;
+  at.B = B; at.H = 8; at.G = G; at.S = S; at.L = L; at.lens = lens; at.chunk = 0;
   return jv::attention64(at, static_cast<hipStream_t>(stream));
 }
 

@@ -86,7 +86,14 @@ __global__ __launch_bounds__(64 * NW) void attn64_kernel(const AttnArgs p) {
     }
   };
 
-  const int nkt = (len + 31) >> 5;
+  // chunk-causal (streaming) mask: this lane's query sees keys < kend; the workgroup only walks key tiles that some
+  // query of it can see (jyutvoice/utils/mask.py:91-126: static chunks, all left chunks)
+  int kend = len, kmax = len;
+  if (p.chunk > 0) {
+    kend = min(len, ((q0 + r32) / p.chunk + 1) * p.chunk);
+    kmax = min(len, ((qt * 32 * NW + 32 * NW - 1) / p.chunk + 1) * p.chunk);
+  }
+  const int nkt = (kmax + 31) >> 5;
   if (nkt > 0) prefetch(0);
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * 32;
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(64 * NW) void attn64_kernel(const AttnArgs p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * half;
-      s[e] = key < len ? s[e] : -INFINITY;
+      s[e] = key < kend ? s[e] : -INFINITY;
       mt = fmaxf(mt, s[e]);
     }
     mt = fmaxf(mt, __shfl_xor(mt, 32));
@@ -264,7 +271,14 @@ __global__ __launch_bounds__(64 * NW) void attn64_x6_kernel(const AttnArgs p) {
     }
   };
 
-  const int nkt = (len + 31) >> 5;
+  // chunk-causal (streaming) mask: this lane's query sees keys < kend; the workgroup only walks key tiles that some
+  // query of it can see (jyutvoice/utils/mask.py:91-126: static chunks, all left chunks)
+  int kend = len, kmax = len;
+  if (p.chunk > 0) {
+    kend = min(len, ((q0 + r32) / p.chunk + 1) * p.chunk);
+    kmax = min(len, ((qt * 32 * NW + 32 * NW - 1) / p.chunk + 1) * p.chunk);
+  }
+  const int nkt = (kmax + 31) >> 5;
   if (nkt > 0) prefetch(0);
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * 32;
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(64 * NW) void attn64_x6_kernel(const AttnArgs p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * half;
-      s[e] = key < len ? s[e] : -INFINITY;
+      s[e] = key < kend ? s[e] : -INFINITY;
       mt = fmaxf(mt, s[e]);
     }
     mt = fmaxf(mt, __shfl_xor(mt, 32));

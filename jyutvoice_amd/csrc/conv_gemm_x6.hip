@@ -310,7 +310,7 @@ int x6_launch(const ConvGemmArgs& a, hipStream_t st) {
 int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st) {
   const int span = (a.ntaps - 1) * a.tap_dil;
   struct Cand { int bm, bn; double eff; size_t lds; };
-  // measured on the estimator shapes (tools_gemm_bench.py): the big tile amortises staging and barriers best
+  // measured on the estimator shapes (tools/gemm_bench.py): the big tile amortises staging and barriers best
   const Cand cands[3] = {{128, 128, 1.0, x6_lds_bytes<128, 128>(a)}, {64, 128, 0.8, x6_lds_bytes<64, 128>(a)},
                          {64, 64, 0.8, x6_lds_bytes<64, 64>(a)}};
   int best = -1;

@@ -116,6 +116,7 @@ struct AttnArgs {
   int B, H;
   int G, S, L;        // row geometry: utterance b, frame t at row G + b*S + t, t < L
   const int* lens;    // [B] valid keys per utterance (device), or null = L
+  int chunk;          // > 0: chunk-causal (streaming) mask -- query i sees keys j < (i / chunk + 1) * chunk; 0: all keys
 };
 int attention64(const AttnArgs& a, hipStream_t st);
 

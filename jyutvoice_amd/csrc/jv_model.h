@@ -98,6 +98,7 @@ struct Context {
   HiftW hift;
   float* noise = nullptr;        // [80][15000] fixed CFM noise (device), supplied by the host
   bool noise_loaded = false;
+  int attn_chunk = 0;            // > 0: streaming (chunk-causal) estimator attention, in frames (jv_flow_set_streaming)
   // workspace
   std::vector<void*> ws_allocs;
   struct FlowWs* flow = nullptr;

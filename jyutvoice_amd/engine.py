@@ -99,6 +99,10 @@ class Engine:
         torch.cuda.synchronize(self.device)
 
     # ---- flow ---------------------------------------------------------------------------------------
+    def set_streaming(self, chunk_frames: int = spec.EST_STATIC_CHUNK):
+        """chunk-causal estimator attention (the reference's streaming=True); 0 = full attention"""
+        check(self.lib.jv_flow_set_streaming(self._h, int(chunk_frames)))
+
     def flow_estimator(self, x, mask_lens, mu, t, spks, cond):
         """[B2,80,T] tensors on the device; mask_lens int32 [B2] or None."""
         B2, _, T = x.shape

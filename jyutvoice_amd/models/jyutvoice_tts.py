@@ -35,6 +35,8 @@ class JyutVoiceTTS:
         self.freeze_encoder, self.freeze_decoder = freeze_encoder, freeze_decoder
         self.device = torch.device(device)
         self._loaded = False
+        self._sd: Dict[str, torch.Tensor] = {}
+        self._missing = list(spec.TTS_INVENTORY)
         if pretrain_path:
             self.load_pretrain(pretrain_path)
 
@@ -47,21 +49,25 @@ class JyutVoiceTTS:
         return self
 
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
-        rt = get_runtime(self.device)
-        sd = state_dict
+        """Same key names / shapes / error text as the reference module.  With strict=False (what `load_pretrain` uses,
+        jyutvoice_tts.py:104) keys accumulate across calls -- e.g. CosyVoice2's flow.pt (`decoder.*`,
+        `spk_embed_affine_layer.*`) first, a fine-tuned encoder/dp checkpoint later -- and the weights go to the GPU once
+        all 1041 tensors are known; until then synthesise() names what is missing (the reference would silently run the
+        missing sub-modules with their random initialisation)."""
         missing = [k for k in spec.TTS_INVENTORY if k not in state_dict]
         unexpected = [k for k in state_dict if k not in spec.TTS_INVENTORY]
         if strict and (missing or unexpected):
             raise RuntimeError(f"Error(s) in loading state_dict for JyutVoiceTTS: Missing key(s): {missing[:6]}; "
                                f"Unexpected key(s): {unexpected[:6]}")
-        if missing:
-            raise RuntimeError(f"cannot run with a partial checkpoint; missing {len(missing)} tensors, e.g. {missing[:4]}")
-        for k, shape in spec.TTS_INVENTORY.items():
-            if tuple(sd[k].shape) != tuple(shape):
-                raise RuntimeError(f"size mismatch for {k}: copying a param with shape {tuple(sd[k].shape)} from checkpoint, "
-                                   f"the shape in current model is {tuple(shape)}.")
-        rt.set_weights(JV_MODEL_TTS, {k: sd[k] for k in spec.TTS_INVENTORY})
-        self._loaded = True
+        for k, v in state_dict.items():
+            if k in spec.TTS_INVENTORY and tuple(v.shape) != tuple(spec.TTS_INVENTORY[k]):
+                raise RuntimeError(f"size mismatch for {k}: copying a param with shape {tuple(v.shape)} from checkpoint, "
+                                   f"the shape in current model is {tuple(spec.TTS_INVENTORY[k])}.")
+        self._sd.update({k: v.detach() for k, v in state_dict.items() if k in spec.TTS_INVENTORY})
+        self._missing = [k for k in spec.TTS_INVENTORY if k not in self._sd]
+        if not self._missing:
+            get_runtime(self.device).set_weights(JV_MODEL_TTS, {k: self._sd[k] for k in spec.TTS_INVENTORY})
+            self._loaded = True
         return missing, unexpected
 
     def load_pretrain(self, pretrain_path):
@@ -76,7 +82,8 @@ class JyutVoiceTTS:
     def synthesise(self, x, x_lengths, lang, tone, word_pos, syllable_pos, spk_embed, prompt_feat, prompt_h=None,
                    n_timesteps=10, temperature=1.0, length_scale=1.0, batched=False):
         if not self._loaded:
-            raise RuntimeError("JyutVoiceTTS: load_state_dict() has not been called")
+            raise RuntimeError(f"JyutVoiceTTS: load_state_dict() has not provided all weights yet; {len(self._missing)} tensors "
+                               f"missing, e.g. {self._missing[:4]}")
         t0 = dt.datetime.now()
         B, Tt = x.shape
         rt = get_runtime(self.device)

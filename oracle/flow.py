@@ -61,14 +61,20 @@ def transformer_block(sd, pre, h, bias):
     return h + F.linear(f, sd[pre + "ff.net.2.weight"], sd[pre + "ff.net.2.bias"])
 
 
-def estimator(sd, x, mask, mu, t, spks, cond, pre="decoder.estimator.", taps=None):
+def estimator(sd, x, mask, mu, t, spks, cond, pre="decoder.estimator.", taps=None, streaming=False, chunk=50):
     """x,mu,cond [B,80,T], mask [B,1,T], t [B], spks [B,80] -> [B,80,T].  decoder.py:917-1018.
 
-    `taps` (optional dict) receives intermediate activations for the golden fixtures."""
+    `taps` (optional dict) receives intermediate activations for the golden fixtures.
+    streaming=True: chunk-causal attention (decoder.py:951-954 -> utils/mask.py:91-126,192-198 with
+    static_chunk_size = chunk, all left chunks): query i sees keys j < (i // chunk + 1) * chunk, and the key mask."""
     temb = time_embedding(sd, t, pre)
     T = x.shape[2]
     h = torch.cat([x, mu, spks.unsqueeze(-1).expand(-1, -1, T), cond], dim=1)
-    bias = ((1.0 - mask) * -1.0e10).unsqueeze(1)          # [B,1,1,T]: every query row sees the key mask
+    allowed = mask.bool().unsqueeze(1)                    # [B,1,1,T]: every query row sees the key mask
+    if streaming:
+        i = torch.arange(T)
+        allowed = allowed & (i[None, :] < ((i // chunk + 1) * chunk)[:, None])[None, None]   # [B,1,T,T]
+    bias = (1.0 - allowed.to(x.dtype)) * -1.0e10
 
     def stage(prefix, h, n_blocks=4):
         h = resnet(sd, prefix + "0.", h, mask, temb)

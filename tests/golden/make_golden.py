@@ -265,6 +265,20 @@ def main():
          down_resnet=taps_r["down_resnet"], down=taps_r["down"], mid0=taps_r["mid0"], mid11=taps_r["mid11"],
          up=taps_r["up"])
 
+    # ---- G10: streaming (chunk-causal) estimator call: static_chunk_size 50, all left chunks (decoder.py:951-954) ----
+    g10 = torch.Generator().manual_seed(10)
+    T10 = 130
+    lens10 = torch.tensor([130, 77])
+    mask10 = (torch.arange(T10)[None] < lens10[:, None]).unsqueeze(1).float()
+    x10 = torch.randn(2, 80, T10, generator=g10)
+    mu10 = torch.randn(2, 80, T10, generator=g10) * mask10
+    cond10 = torch.randn(2, 80, T10, generator=g10) * 0.5 * mask10
+    spks10 = torch.randn(2, 80, generator=g10)
+    t10 = torch.tensor([0.6, 0.6])
+    out10 = est(x10, mask10, mu10, t10, spks10, cond10, streaming=True)
+    report["G10 streaming out"] = maxdiff(out10, oflow.estimator(tts_sd, x10, mask10, mu10, t10, spks10, cond10, streaming=True))
+    save("G10_streaming", x=x10, mask=mask10, mu=mu10, t=t10, spks=spks10, cond=cond10, out=out10)
+
     # ---- G6: padded batch equals per-utterance calls ---------------------------------------------
     o0 = est(xin[:1], mask[:1], mu[:1], t[:1], spks[:1], cond[:1])
     o1 = est(xin[1:, :, :20], mask[1:, :, :20], mu[1:, :, :20], t[1:], spks[1:], cond[1:, :, :20])

@@ -102,3 +102,21 @@ def test_registry_matches_spec(eng):
     from jyutvoice_amd.engine import JV_MODEL_HIFT, JV_MODEL_TTS
     assert eng.registry(JV_MODEL_TTS) == {k: tuple(v) for k, v in spec.TTS_INVENTORY.items()}
     assert eng.registry(JV_MODEL_HIFT) == {k: tuple(v) for k, v in spec.HIFT_INVENTORY.items()}
+
+
+def test_streaming_chunk_causal_golden(eng, tts_sd):
+    """streaming=True of the reference estimator (chunk 50): golden G10, and the oracle on an odd chunk size"""
+    from oracle import flow as oflow
+    g = load_golden("G10_streaming")
+    lens = g["mask"].sum(dim=(1, 2)).to(torch.int32)
+    try:
+        eng.set_streaming(50)
+        out = eng.flow_estimator(g["x"], lens, g["mu"], g["t"], g["spks"], g["cond"])
+        assert md(out, g["out"]) <= 1e-4
+        eng.set_streaming(7)
+        want = oflow.estimator(tts_sd, g["x"], g["mask"], g["mu"], g["t"], g["spks"], g["cond"], streaming=True, chunk=7)
+        assert md(eng.flow_estimator(g["x"], lens, g["mu"], g["t"], g["spks"], g["cond"]), want) <= 1e-4
+    finally:
+        eng.set_streaming(0)
+    full = eng.flow_estimator(g["x"], lens, g["mu"], g["t"], g["spks"], g["cond"])
+    assert md(full, g["out"]) > 1e-2       # the mask really changes the result

@@ -66,3 +66,18 @@ def test_shard_range():
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_partial_checkpoints_accumulate():
+    """load_pretrain semantics (strict=False): flow.pt-style partial checkpoints merge; nothing runs until complete"""
+    import jyutvoice_amd
+    tts, _ = jyutvoice_amd.build_default()
+    sd = synth.tts_state_dict()
+    flow_pt = {k: v for k, v in sd.items() if k.startswith(("decoder.", "spk_embed_affine_layer."))}
+    flow_pt["optimizer.junk"] = torch.zeros(1)
+    missing, unexpected = tts.load_state_dict(flow_pt, strict=False)
+    assert len(missing) == 117 + 12 and unexpected == ["optimizer.junk"] and not tts._loaded
+    with pytest.raises(RuntimeError, match="129 tensors missing"):
+        tts.synthesise(*([torch.zeros(1, 4, dtype=torch.int64)] * 6), torch.zeros(1, 192), None)
+    with pytest.raises(RuntimeError, match="size mismatch for dp.proj.bias"):
+        tts.load_state_dict({"dp.proj.bias": torch.zeros(3)}, strict=False)

@@ -108,3 +108,9 @@ def test_batch_size_error(tts_sd, noise):
     with pytest.raises(ValueError, match="requires batch_size=1"):
         otts.synthesise(tts_sd, noise, b["x"], b["x_lengths"], b["lang"], b["tone"], b["word_pos"], b["syllable_pos"],
                         b["spk_embed"], None)
+
+
+def test_streaming_estimator(tts_sd):
+    g = load_golden("G10_streaming")
+    out = oflow.estimator(tts_sd, g["x"], g["mask"], g["mu"], g["t"], g["spks"], g["cond"], streaming=True)
+    assert md(out, g["out"]) <= 2e-5

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise a tools_profile.sh output directory: per-kernel time from the kernel-trace stats and HBM bytes per launch
+"""Summarise a tools/profile.sh output directory: per-kernel time from the kernel-trace stats and HBM bytes per launch
 from the PMC passes (FETCH_SIZE doubled, as MI355X_MICROARCH.md prescribes for gfx950; both counters are in KiB)."""
 import csv
 import glob
