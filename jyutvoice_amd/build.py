@@ -18,6 +18,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libjyutvoice_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+if os.environ.get("JV_TUNING"):      # ablation switches + in-kernel stamps (tools/gemm_bench.py); use with --force
+    FLAGS.append("-DJV_TUNING")
 
 
 def _hipcc() -> str:

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p, co
   }
 
   unsigned long long t_start = 0, t_loop = 0;
-  if (p.stamps) t_start = __builtin_amdgcn_s_memtime();
+  if (JV_STAMP(p)) t_start = __builtin_amdgcn_s_memtime();
   const int ntaps = p.ntaps, dil = p.tap_dil;
   const int win = BM + (ntaps - 1) * dil;
   const int na = (win + 31) >> 5;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p, co
   // De-phase the workgroups that share a CU: all blocks start together, run equally long main loops and would reach
   // their (HBM-write-bound) epilogues together, leaving the matrix pipe idle.  Blocks of the second dispatch wave
   // start half a tile late, so one workgroup's epilogue/prologue runs under the other's MFMAs from then on.
-  if ((p.ablate & 32) && blockIdx.x >= 256 && blockIdx.x < 512) {
+  if (JV_ABLATE(p, 32) && blockIdx.x >= 256 && blockIdx.x < 512) {
     const int naps = (nsteps * MT * NT * 1024) / 8128 / 2 + 1;     // ~half of this tile's MFMA time
     for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
   }
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p, co
   if (ntaps == 1 && nchunks > 1) load_A(32);                          // A of chunk 1 is stored during step 0
   __syncthreads();
 
-  if (p.stamps) t_loop = __builtin_amdgcn_s_memtime();
+  if (JV_STAMP(p)) t_loop = __builtin_amdgcn_s_memtime();
   int c = 0, j = 0;
   for (int s = 0; s < nsteps; ++s) {
     const float* la = ldsA0 + (c & 1) * win * LDS_STRIDE + (wm * WM + r32 + j * dil) * LDS_STRIDE + 16 * half;
@@ -200,19 +200,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p, co
     int j1 = j + 1, c1 = c;                      // step s+1
     if (j1 == ntaps) { j1 = 0; c1 = c + 1; }
     if (s + 1 < nsteps) {
-      if (!(p.ablate & 2)) {
+      if (!JV_ABLATE(p, 2)) {
         store_W((s + 1) & 1);
         if (j == ntaps - 1) store_A(c1 * 32, c1 & 1);
       }
       int j2 = j1 + 1, c2 = c1;                  // step s+2
       if (j2 == ntaps) { j2 = 0; c2 = c1 + 1; }
-      if (!(p.ablate & 1)) {
+      if (!JV_ABLATE(p, 1)) {
         if (s + 2 < nsteps) load_W(j2, c2 * 32);
         if (j1 == ntaps - 1 && c1 + 1 < nchunks) load_A((c1 + 1) * 32);   // stored during step s+1
       }
     }
     mfma_quads(la, lw, 2);
-    if (!(p.ablate & 4)) __syncthreads();
+    if (!JV_ABLATE(p, 4)) __syncthreads();
     j = j1;
     c = c1;
   }
@@ -250,7 +250,7 @@ int launch2(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
   dim3 grid(tiles_m * tiles_n, 1, nbatch);
   const bool prof = prof_on();
   if (prof) prof_begin(st);
-  if (getenv("JV_STAMPS")) {   // diagnostic only: synchronous, prints phase shares of this launch
+  if (tuning_env("JV_STAMPS")) {   // diagnostic only: synchronous, prints phase shares of this launch
     static unsigned long long* dbuf = nullptr;
     const size_t nb = (size_t)grid.x * 4;
     if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 4 * 65536);
@@ -375,7 +375,7 @@ int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
     const double cost = (double)cdivl(tiles, 256) * cands[i].bm * cands[i].bn / cands[i].eff;
     if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
   }
-  if (const char* ab = getenv("JV_ABLATE")) const_cast<ConvGemmArgs&>(a).ablate = atoi(ab);
+  if (const char* ab = tuning_env("JV_ABLATE")) const_cast<ConvGemmArgs&>(a).ablate = atoi(ab);
   if (const char* force = getenv("JV_TILE")) {   // tuning aid: force a tile variant (0, 1, 2)
     const int f = atoi(force);
     if (f >= 0 && f <= 2 && !((f == 0 && 128 + span > 192) || (f > 0 && 64 + span > 128))) best = f;

@@ -25,8 +25,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
   unsigned long long t_epi = 0, t_loop2 = 0, t_p0 = 0;
   // Per-row operands (mask, residuals, previous value) of four rows are fetched together before any arithmetic: a
   // rolled row loop would expose one global-load latency per row (measured: 33 K cycles per 128x128 tile).
-  if (p.stamps) t_epi = __builtin_amdgcn_s_memtime();
-  if (p.ablate & 16) return;
+  if (JV_STAMP(p)) t_epi = __builtin_amdgcn_s_memtime();
+  if (JV_ABLATE(p, 16)) return;
   constexpr int ES = WN + 4;
   constexpr int C4 = WN / 4;                     // float4 columns per row
   constexpr int RPI = 64 / C4;                   // rows per wave-instruction
@@ -44,7 +44,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
       for (int e = 0; e < 4; ++e) bb[e] = (n + e < p.N) ? p.bias[n + e] : 0.f;
   }
   if constexpr (EPI != 4) {
-    if (!(p.ablate & 256)) {
+    if (!JV_ABLATE(p, 256)) {
       // lean path, straight from the accumulators in MFMA layout: register e of a 32x32 tile is row (e&3)+8(e>>2)+4*half,
       // column lane&31, so each half-wave stores 128 contiguous bytes per instruction -- no LDS round trip, no barrier.
       constexpr bool E_GELU = (EPI & 1) != 0, E_RES = (EPI & 2) != 0;
@@ -70,10 +70,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
             float t = acc[mt][nt][e] + bn;
             if constexpr (E_GELU) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752440f));
             if constexpr (E_RES) t += r[e];
-            if (nok && m < p.M && !(p.ablate & 64)) out[(long)m * p.ldo + nn] = t;   // (non-temporal stores: no gain, A/B'd)
+            if (nok && m < p.M && !JV_ABLATE(p, 64)) out[(long)m * p.ldo + nn] = t;   // (non-temporal stores: no gain, A/B'd)
           }
         }
-      if (p.stamps && tid == 0) {
+      if (JV_STAMP(p) && tid == 0) {
         unsigned long long* d = p.stamps + (size_t)blockIdx.x * 4;
         d[0] = t_start; d[1] = t_loop; d[2] = t_epi; d[3] = __builtin_amdgcn_s_memtime();
       }
@@ -88,7 +88,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
 #pragma unroll
       for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * half) * ES + nt * 32 + r32] = acc[mt][nt][e];
     __syncthreads();
-    if (p.stamps && mt == 0) t_loop2 = __builtin_amdgcn_s_memtime();
+    if (JV_STAMP(p) && mt == 0) t_loop2 = __builtin_amdgcn_s_memtime();
     if constexpr (EPI != 4) {
       // lean path (host guarantees N % 4 == 0, 16-byte aligned rows, no mask / row vector / second residual / scaling):
       // out = act(acc + bias) (+ res1).  All residual loads of the pass are issued before any arithmetic.
@@ -112,7 +112,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
           for (int e = 0; e < 4; ++e) t[e] = 0.5f * t[e] * (1.f + erff(t[e] * 0.70710678118654752440f));
         }
         if constexpr (E_RES) t += r[it];
-        if (nin && mrow + it * RPI < p.M && !(p.ablate & 64)) *reinterpret_cast<f32x4*>(ob + (long)(it * RPI) * p.ldo) = t;
+        if (nin && mrow + it * RPI < p.M && !JV_ABLATE(p, 64)) *reinterpret_cast<f32x4*>(ob + (long)(it * RPI) * p.ldo) = t;
       }
       return;
     }
@@ -168,7 +168,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
         }
         float* o = out + (long)m * p.ldo + n;
         if (vec) {
-          if (!(p.ablate & 64) || res[0] == 12345.678f) *reinterpret_cast<f32x4*>(o) = res;
+          if (!JV_ABLATE(p, 64) || res[0] == 12345.678f) *reinterpret_cast<f32x4*>(o) = res;
         } else {
           for (int e = 0; e < 4; ++e)
             if (n + e < p.N) o[e] = res[e];
@@ -177,9 +177,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
     }
   };
   pass(std::integral_constant<int, 0>{});
-  if (p.stamps) t_p0 = __builtin_amdgcn_s_memtime();
+  if (JV_STAMP(p)) t_p0 = __builtin_amdgcn_s_memtime();
   if constexpr (MT > 1) pass(std::integral_constant<int, 1>{});
-  if (p.stamps && tid == 0) {
+  if (JV_STAMP(p) && tid == 0) {
     unsigned long long* d = p.stamps + (size_t)blockIdx.x * 4;
     d[0] = t_start; d[1] = t_loop; d[2] = t_epi; d[3] = __builtin_amdgcn_s_memtime();
   }

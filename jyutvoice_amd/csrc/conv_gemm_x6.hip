@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
   const float* A = p.A;
   float* out = p.out;
   unsigned long long t_start = 0, t_loop = 0;
-  if (p.stamps) t_start = __builtin_amdgcn_s_memtime();
+  if (JV_STAMP(p)) t_start = __builtin_amdgcn_s_memtime();
 
   const int ntaps = p.ntaps, dil = p.tap_dil;
   const int win = BM + (ntaps - 1) * dil;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
   const int nsteps = nchunks * ntaps;
   load_A(0);
   load_W(0, 0);
-  if (p.stamps) t_loop = __builtin_amdgcn_s_memtime();
+  if (JV_STAMP(p)) t_loop = __builtin_amdgcn_s_memtime();
   int c = 0, j = 0;
   for (int s = 0; s < nsteps; ++s) {
     __syncthreads();
@@ -240,7 +240,7 @@ int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
   const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
   const bool prof = prof_on();
   if (prof) prof_begin(st);
-  if (getenv("JV_STAMPS")) {   // diagnostic only: synchronous, prints phase shares of this launch
+  if (tuning_env("JV_STAMPS")) {   // diagnostic only: synchronous, prints phase shares of this launch
     static unsigned long long* dbuf = nullptr;
     const unsigned nwg = tiles_m * tiles_n;
     if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 4 * 65536);

@@ -11,6 +11,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
 #include <string>
 
 #define JV_OK 0
@@ -19,6 +21,16 @@
 #define JV_ERR_HIP 3
 #define JV_ERR_SHAPE 4
 #define JV_ERR_NAME 5
+
+// Tuning aids (ablation switches, in-kernel phase stamps) compile to nothing unless the library is built with
+// JV_TUNING=1 python -m jyutvoice_amd.build --force (tools/gemm_bench.py documents the switches).
+#ifdef JV_TUNING
+#define JV_ABLATE(p, bit) (((p).ablate & (bit)) != 0)
+#define JV_STAMP(p) ((p).stamps != nullptr)
+#else
+#define JV_ABLATE(p, bit) (false)
+#define JV_STAMP(p) (false)
+#endif
 
 namespace jv {
 
@@ -37,6 +49,12 @@ int fail(int code, const std::string& msg);      // set_error + return code
     int _rc = (expr);             \
     if (_rc != JV_OK) return _rc; \
   } while (0)
+
+#ifdef JV_TUNING
+inline const char* tuning_env(const char* name) { return getenv(name); }
+#else
+inline const char* tuning_env(const char*) { return nullptr; }
+#endif
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline long cdivl(long a, long b) { return (a + b - 1) / b; }

@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the conv_gemm / attention kernels on the estimator's shapes at C3 (M = 19.3K rows).
-    JV_TILE=0|1|2 python tools/gemm_bench.py      (tuning aid; prints TFLOP/s per shape)"""
+    JV_TILE=0|1|2 python tools/gemm_bench.py      (tuning aid; prints TFLOP/s per shape)
+
+Switches: JV_ONLY=qkv|ff1|ff2|out|res|conv3|attn (shape filter), JV_M=rows, JV_OP_X6=1 (bf16x6 main loop), JV_TILE (force tile),
+JV_ATTN_FP32=1.  With a tuning build (JV_TUNING=1 python -m jyutvoice_amd.build --force): JV_ABLATE=bits (1 no global loads in the
+loop, 2 no LDS stores, 4 no barrier, 16 no epilogue, 64 no output stores, 256 slab epilogue) and JV_STAMPS=1 (per-workgroup
+s_memtime phase breakdown on stderr)."""
 import math
 import os
 import sys
