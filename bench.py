@@ -112,10 +112,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())   # one rank per GPU on the real node; the modulo only matters
+    torch.cuda.set_device(dev_index)                             # when rehearsing several ranks on a 1-GPU box (gloo)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("JV_DIST_BACKEND", "nccl")      # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import jyutvoice_amd
     from jyutvoice_amd import dist as jdist
