@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libjyutvoice_hip.so")
+LIB_PATH = os.environ.get("JYUTVOICE_HIP_LIB") or os.path.join(HERE, "libjyutvoice_hip.so")
 
 JV_MODEL_TTS = 0
 JV_MODEL_HIFT = 1

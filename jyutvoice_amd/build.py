@@ -15,9 +15,13 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, "build")
-LIB = os.path.join(HERE, "libjyutvoice_hip.so")
+# JV_BUILD_TAG=x (tuning aid): objects in build/x/, library libjyutvoice_hip.x.so -- load it with JYUTVOICE_HIP_LIB=<path>;
+# JV_EXTRA_FLAGS adds compiler flags to that variant, so two builds can be A/B'd inside one GPU session.
+TAG = os.environ.get("JV_BUILD_TAG", "")
+OBJ = os.path.join(CSRC, "build", TAG) if TAG else os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, f"libjyutvoice_hip.{TAG}.so" if TAG else "libjyutvoice_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+FLAGS += os.environ.get("JV_EXTRA_FLAGS", "").split()
 if os.environ.get("JV_TUNING"):      # ablation switches + in-kernel stamps (tools/gemm_bench.py); use with --force
     FLAGS.append("-DJV_TUNING")
 

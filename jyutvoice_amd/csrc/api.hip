@@ -216,7 +216,7 @@ int jv_op_conv_gemm(const float* A, int64_t a_rows, int M, int Cin, int ntaps, i
 }
 
 int jv_op_attention(const float* qkv, const int32_t* lens, int B, int G, int S, int L, float* out, void* stream) {
-  jv::AttnArgs at;
+  jv::AttnArgs at{};
   at.qkv = qkv; at.ld = 1536; at.k_off = 512; at.v_off = 1024; at.out = out; at.ldo = 512;
   at.B = B; at.H = 8; at.G = G; at.S = S; at.L = L; at.lens = lens; at.chunk = 0;
   return jv::attention64(at, static_cast<hipStream_t>(stream));

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "jv_common.h"
+#include "jv_device.h"
 
 namespace jv {
 
@@ -201,8 +202,8 @@ __device__ __forceinline__ f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[
   return c;
 }
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void attn64_x6_kernel(const AttnArgs p) {
+template <int NW, int WPE>
+__global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char ldsK[3 * 32 * AK_ROWB];
   __shared__ __attribute__((aligned(16))) unsigned char ldsV[3 * 64 * AV_ROWB];
   constexpr int NT = 64 * NW;
@@ -240,11 +241,16 @@ __global__ __launch_bounds__(64 * NW) void attn64_x6_kernel(const AttnArgs p) {
         t0 = *reinterpret_cast<const f32x4*>(src + 16 * s);
         t1 = *reinterpret_cast<const f32x4*>(src + 16 * s + 4);
       }
+      u32x4 qh, qm, ql;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float x = (e < 4 ? t0[e & 3] : t1[e & 3]) * (0.125f * 1.44269504088896340736f);
-        JV_SPLIT3(x, q[s][0][e], q[s][1][e], q[s][2][e]);
+      for (int e = 0; e < 4; ++e) {
+        constexpr float sc = 0.125f * 1.44269504088896340736f;
+        const float x0 = (e < 2 ? t0[2 * e] : t1[2 * e - 4]) * sc, x1 = (e < 2 ? t0[2 * e + 1] : t1[2 * e - 3]) * sc;
+        { const Split3 t_ = split3_pair(x0, x1); qh[e] = t_.h; qm[e] = t_.m; ql[e] = t_.l; }
       }
+      q[s][0] = __builtin_bit_cast(bf16x8, qh);
+      q[s][1] = __builtin_bit_cast(bf16x8, qm);
+      q[s][2] = __builtin_bit_cast(bf16x8, ql);
     }
   }
 
@@ -256,18 +262,22 @@ __global__ __launch_bounds__(64 * NW) void attn64_x6_kernel(const AttnArgs p) {
   f32x4 pk[NKL];
   float pv[KPT];
   const int vd = tid & 63, vkg = tid >> 6;
+  // Rows past the last valid key are clamped to it instead of branched around: their scores are masked to -inf below, so
+  // P is exactly 0 there and whatever finite K/V values were staged do not matter.
+  const float* const kbase = p.qkv + rowbase * p.ld + p.k_off + h * 64;    // wave-uniform bases, 32-bit offsets per lane
+  const float* const vbase = p.qkv + rowbase * p.ld + p.v_off + h * 64 + vd;
+  const unsigned uld = (unsigned)p.ld;
   auto prefetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NKL; ++i) {
       const int idx = tid + i * NT;
-      const int key = idx >> 4, c4 = idx & 15;
-      pk[i] = (k0 + key < len) ? *reinterpret_cast<const f32x4*>(p.qkv + (rowbase + k0 + key) * p.ld + p.k_off + h * 64 + 4 * c4)
-                               : f32x4{0.f, 0.f, 0.f, 0.f};
+      const unsigned key = (unsigned)min(k0 + (idx >> 4), len - 1);
+      pk[i] = *reinterpret_cast<const f32x4*>(kbase + (key * uld + 4u * (idx & 15)));
     }
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-      const int key = vkg * KPT + i;
-      pv[i] = (k0 + key < len) ? p.qkv[(rowbase + k0 + key) * p.ld + p.v_off + h * 64 + vd] : 0.f;
+      const unsigned key = (unsigned)min(k0 + vkg * KPT + i, len - 1);
+      pv[i] = vbase[key * uld];
     }
   };
 
@@ -282,33 +292,35 @@ __global__ __launch_bounds__(64 * NW) void attn64_x6_kernel(const AttnArgs p) {
   if (nkt > 0) prefetch(0);
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * 32;
-    __syncthreads();
+    if (!JV_ABLATE(p, 4)) __syncthreads();
+    if (!JV_ABLATE(p, 2)) {
 #pragma unroll
     for (int i = 0; i < NKL; ++i) {
       const int idx = tid + i * NT;
       const int key = idx >> 4, c4 = idx & 15;
-      bf16x4 hh, mm, ll;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) JV_SPLIT3(pk[i][e], hh[e], mm[e], ll[e]);
+      u32x2 hh, mm, ll;
+      { const Split3 t_ = split3_pair(pk[i][0], pk[i][1]); hh[0] = t_.h; mm[0] = t_.m; ll[0] = t_.l; }
+      { const Split3 t_ = split3_pair(pk[i][2], pk[i][3]); hh[1] = t_.h; mm[1] = t_.m; ll[1] = t_.l; }
       unsigned char* dst = ldsK + key * AK_ROWB + c4 * 8;
-      *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, hh);
-      *reinterpret_cast<u32x2*>(dst + 32 * AK_ROWB) = __builtin_bit_cast(u32x2, mm);
-      *reinterpret_cast<u32x2*>(dst + 64 * AK_ROWB) = __builtin_bit_cast(u32x2, ll);
+      *reinterpret_cast<u32x2*>(dst) = hh;
+      *reinterpret_cast<u32x2*>(dst + 32 * AK_ROWB) = mm;
+      *reinterpret_cast<u32x2*>(dst + 64 * AK_ROWB) = ll;
     }
 #pragma unroll
     for (int g = 0; g < KPT / 4; ++g) {         // 4 consecutive keys stay consecutive under the bit swap
       const int key = vkg * KPT + 4 * g;
       const int pos = (key & 0x13) | ((key & 4) << 1) | ((key & 8) >> 1);
-      bf16x4 hh, mm, ll;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) JV_SPLIT3(pv[4 * g + e], hh[e], mm[e], ll[e]);
+      u32x2 hh, mm, ll;
+      { const Split3 t_ = split3_pair(pv[4 * g], pv[4 * g + 1]); hh[0] = t_.h; mm[0] = t_.m; ll[0] = t_.l; }
+      { const Split3 t_ = split3_pair(pv[4 * g + 2], pv[4 * g + 3]); hh[1] = t_.h; mm[1] = t_.m; ll[1] = t_.l; }
       unsigned char* dst = ldsV + vd * AV_ROWB + pos * 2;
-      *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, hh);
-      *reinterpret_cast<u32x2*>(dst + 64 * AV_ROWB) = __builtin_bit_cast(u32x2, mm);
-      *reinterpret_cast<u32x2*>(dst + 128 * AV_ROWB) = __builtin_bit_cast(u32x2, ll);
+      *reinterpret_cast<u32x2*>(dst) = hh;
+      *reinterpret_cast<u32x2*>(dst + 64 * AV_ROWB) = mm;
+      *reinterpret_cast<u32x2*>(dst + 128 * AV_ROWB) = ll;
     }
-    __syncthreads();
-    if (kt + 1 < nkt) prefetch(k0 + 32);
+    }
+    if (!JV_ABLATE(p, 4)) __syncthreads();
+    if (kt + 1 < nkt && !JV_ABLATE(p, 1)) prefetch(k0 + 32);
     if (!active) continue;
 
     // S^T[key][query] = sum_d K[key][d] * Q[query][d]
@@ -321,43 +333,56 @@ __global__ __launch_bounds__(64 * NW) void attn64_x6_kernel(const AttnArgs p) {
       bf16x8 a[3];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(kr + pl * 32 * AK_ROWB + 32 * st);
-      s = mfma6(a, q[st], s);
+      if (!JV_ABLATE(p, 16)) s = mfma6(a, q[st], s);
+      else s[st] += (float)a[0][0] + (float)a[1][1] + (float)a[2][2];
     }
-    float mt = -INFINITY;
+    if (!JV_ABLATE(p, 32)) {
+    if (__builtin_amdgcn_ballot_w64(k0 + 32 > kend) != 0) {     // wave-uniform: only tiles that straddle a mask edge
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * half;
-      s[e] = key < kend ? s[e] : -INFINITY;
-      mt = fmaxf(mt, s[e]);
+      for (int e = 0; e < 16; ++e) {
+        const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        s[e] = key < kend ? s[e] : -INFINITY;
+      }
     }
+    float mt = s[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mt = fmaxf(mt, s[e]);
     mt = fmaxf(mt, __shfl_xor(mt, 32));
     const float m_new = fmaxf(m_run, mt);
-    const float alpha = exp2f(m_run - m_new);
+    // v_exp_f32 directly: exp2f() wraps it in denormal-range scaling (6 more VALU ops per score); weights below 2^-126
+    // flush to zero instead, far under the fp32 rounding of the row sum
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float lt = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      s[e] = exp2f(s[e] - m_new);
+      s[e] = __builtin_amdgcn_exp2f(s[e] - m_new);
       lt += s[e];
     }
     lt += __shfl_xor(lt, 32);
     l_run = l_run * alpha + lt;
     m_run = m_new;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {        // the running maximum moved for some query of this wave
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+      for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+    }
+    }
     // O^T[d][query] += sum_key V[key][d] * P[query][key]
     const unsigned char* vr = ldsV + r32 * AV_ROWB + 16 * half;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-      bf16x8 pb[3];
+      u32x4 ph, pm, pl_;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) JV_SPLIT3(s[8 * st + e], pb[0][e], pb[1][e], pb[2][e]);
+      for (int e = 0; e < 4; ++e) { const Split3 t_ = split3_pair(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]); ph[e] = t_.h; pm[e] = t_.m; pl_[e] = t_.l; }
+      const bf16x8 pb[3] = {__builtin_bit_cast(bf16x8, ph), __builtin_bit_cast(bf16x8, pm), __builtin_bit_cast(bf16x8, pl_)};
       bf16x8 a[3];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(vr + pl * 64 * AV_ROWB + 32 * st);
-      o0 = mfma6(a, pb, o0);
+      if (!JV_ABLATE(p, 8)) o0 = mfma6(a, pb, o0);
+      else o0[st] += (float)a[0][0] + (float)a[1][1] + (float)a[2][2] + (float)pb[0][0] + (float)pb[1][1] + (float)pb[2][2];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(vr + (pl * 64 + 32) * AV_ROWB + 32 * st);
-      o1 = mfma6(a, pb, o1);
+      if (!JV_ABLATE(p, 8)) o1 = mfma6(a, pb, o1);
+      else o1[st] += (float)a[0][0] + (float)a[1][1] + (float)a[2][2];
     }
   }
 
@@ -385,14 +410,18 @@ int attention64(const AttnArgs& a, hipStream_t st) {
   // bf16x6: staging (split + V transpose) is per thread, so the 4-wave workgroup is ~1.4x faster per query row
   // (measured 110 vs 76 TFLOP/s): prefer it unless its padding costs more than that
   if (!fp32_path && round_up(a.L, 128) * 10 <= round_up(a.L, 64) * 13) waste4 = -1;
+  static const int wpe = getenv("JV_ATTN_WPE") ? atoi(getenv("JV_ATTN_WPE")) : 2;
+  if (const char* ab = tuning_env("JV_ABLATE")) const_cast<AttnArgs&>(a).ablate = atoi(ab);
   const bool prof = prof_on();
   if (prof) prof_begin(st);
   if (waste4 <= waste2) {
     if (fp32_path) hipLaunchKernelGGL((attn64_kernel<4>), dim3(cdiv(a.L, 128) * a.H * a.B), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn64_x6_kernel<4>), dim3(cdiv(a.L, 128) * a.H * a.B), dim3(256), 0, st, a);
+    else if (wpe == 2) hipLaunchKernelGGL((attn64_x6_kernel<4, 2>), dim3(cdiv(a.L, 128) * a.H * a.B), dim3(256), 0, st, a);
+    else if (wpe == 4) hipLaunchKernelGGL((attn64_x6_kernel<4, 4>), dim3(cdiv(a.L, 128) * a.H * a.B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn64_x6_kernel<4, 3>), dim3(cdiv(a.L, 128) * a.H * a.B), dim3(256), 0, st, a);
   } else {
     if (fp32_path) hipLaunchKernelGGL((attn64_kernel<2>), dim3(cdiv(a.L, 64) * a.H * a.B), dim3(128), 0, st, a);
-    else hipLaunchKernelGGL((attn64_x6_kernel<2>), dim3(cdiv(a.L, 64) * a.H * a.B), dim3(128), 0, st, a);
+    else hipLaunchKernelGGL((attn64_x6_kernel<2, 2>), dim3(cdiv(a.L, 64) * a.H * a.B), dim3(128), 0, st, a);
   }
   if (prof) {
     // algorithmic (full-length) figure of SURVEY.md 8(d): QK^T + PV = 4*L*L*64 per head; q,k,v,o once

@@ -358,6 +358,7 @@ int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
     return ln_epilogue_rows(a.out, a.ln_g, a.ln_b, a.ln_eps, a.M, a.N, a.act, a.rowmask_out, a.rowvec, a.row_sample,
                             a.rowvec_ld, a.res1, a.ldr1, a.out_scale, st);
   }
+  if (const char* ab = tuning_env("JV_ABLATE")) const_cast<ConvGemmArgs&>(a).ablate = atoi(ab);
   if (a.W3 && nbatch == 1 && (a.ldw & 7) == 0 && !getenv("JV_NO_X6")) return conv_gemm_x6(a, st);
   // Tile choice: the kernel is MFMA-bound, so cost ~ (#workgroup waves over 256 CUs) x tile area, with a mild penalty
   // for the smaller tiles' lower operand reuse; a variant must fit two workgroups' double-buffered LDS on a CU.
@@ -375,7 +376,6 @@ int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
     const double cost = (double)cdivl(tiles, 256) * cands[i].bm * cands[i].bn / cands[i].eff;
     if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
   }
-  if (const char* ab = tuning_env("JV_ABLATE")) const_cast<ConvGemmArgs&>(a).ablate = atoi(ab);
   if (const char* force = getenv("JV_TILE")) {   // tuning aid: force a tile variant (0, 1, 2)
     const int f = atoi(force);
     if (f >= 0 && f <= 2 && !((f == 0 && 128 + span > 192) || (f > 0 && 64 + span > 128))) best = f;

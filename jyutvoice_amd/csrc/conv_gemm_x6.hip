@@ -172,13 +172,15 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
   if (JV_STAMP(p)) t_loop = __builtin_amdgcn_s_memtime();
   int c = 0, j = 0;
   for (int s = 0; s < nsteps; ++s) {
-    __syncthreads();
-    if (j == 0) store_A(c * 32);
-    store_W();
-    __syncthreads();
+    if (!JV_ABLATE(p, 4)) __syncthreads();
+    if (!JV_ABLATE(p, 2)) {
+      if (j == 0) store_A(c * 32);
+      store_W();
+    }
+    if (!JV_ABLATE(p, 4)) __syncthreads();
     int j2 = j + 1, c2 = c;
     if (j2 == ntaps) { j2 = 0; c2 = c + 1; }
-    if (s + 1 < nsteps) {
+    if (s + 1 < nsteps && !JV_ABLATE(p, 1)) {
       if (j2 == 0) load_A(c2 * 32);
       load_W(j2, c2 * 32);
     }
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           f32x16 t = acc[mt][nt];
+          if (JV_ABLATE(p, 8)) continue;
           t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][2], b[nt][0], t, 0, 0, 0);   // smallest terms first
           t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][0], b[nt][2], t, 0, 0, 0);
           t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][1], b[nt][1], t, 0, 0, 0);
@@ -246,17 +249,30 @@ int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
     if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 4 * 65536);
     ConvGemmArgs b = a;
     b.stamps = nwg <= 65536 ? dbuf : nullptr;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, st);
     hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2>), dim3(nwg), dim3(256), lds, st, b, tiles_n);
+    (void)hipEventRecord(e1, st);
     (void)hipStreamSynchronize(st);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     if (b.stamps) {
       std::vector<unsigned long long> h((size_t)nwg * 4);
       (void)hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
       double pro = 0, loop = 0, epi = 0;
+      unsigned long long t0 = ~0ull, t1 = 0;
       for (unsigned i = 0; i < nwg; ++i) {
         pro += (double)(h[4 * i + 1] - h[4 * i]); loop += (double)(h[4 * i + 2] - h[4 * i + 1]); epi += (double)(h[4 * i + 3] - h[4 * i + 2]);
+        if (h[4 * i] < t0) t0 = h[4 * i];
+        if (h[4 * i + 3] > t1) t1 = h[4 * i + 3];
       }
-      fprintf(stderr, "[stamps x6] %dx%d grid %u: prologue %.0f  loop %.0f  epilogue %.0f cycles avg per workgroup\n", BM, BN, nwg,
-              pro / nwg, loop / nwg, epi / nwg);
+      const double span = (double)(t1 - t0);
+      fprintf(stderr, "[stamps x6] %dx%d grid %u: prologue %.0f  loop %.0f  epilogue %.0f ticks avg per workgroup; span %.0f ticks, %.1f us by events (%.1f ticks/us); mean resident workgroups %.1f\n",
+              BM, BN, nwg, pro / nwg, loop / nwg, epi / nwg, span, ms * 1e3, span / (ms * 1e3), (pro + loop + epi) / span);
     }
     return JV_OK;
   }

@@ -139,7 +139,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     JV_TRY(layernorm_rows(h, nullptr, w.ln, b.n1.g, b.n1.b, 1e-5f, g.M, 256, nullptr, st));
     ConvGemmArgs a = base_args(g, w.ln, 256, b.qkv, w.qkv, 1536);
     JV_TRY(conv_gemm(a, 1, st));
-    AttnArgs at;
+    AttnArgs at{};
     at.qkv = w.qkv; at.ld = 1536; at.k_off = 512; at.v_off = 1024; at.out = w.att; at.ldo = 512;
     at.B = B2; at.H = EST_HEADS; at.G = FLOW_G; at.S = g.S; at.L = g.T; at.lens = w.lens2;
     at.chunk = c.attn_chunk;

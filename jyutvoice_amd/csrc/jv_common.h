@@ -135,6 +135,7 @@ struct AttnArgs {
   int G, S, L;        // row geometry: utterance b, frame t at row G + b*S + t, t < L
   const int* lens;    // [B] valid keys per utterance (device), or null = L
   int chunk;          // > 0: chunk-causal (streaming) mask -- query i sees keys j < (i / chunk + 1) * chunk; 0: all keys
+  int ablate;         // tuning aid (JV_ABLATE): 1 no K/V loads, 2 no split + LDS stores, 4 no barriers, 8 no PV, 16 no QK^T, 32 no softmax
 };
 int attention64(const AttnArgs& a, hipStream_t st);
 

@@ -18,4 +18,22 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
+// bf16x3 split of two fp32 values at once: x ~= h + m + l to 24 bits (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m),
+// round to nearest even).  Returns each plane as one dword holding the pair (element 0 in the low half), the form
+// v_cvt_pk_bf16_f32 produces and the MFMA operands consume.
+typedef float jv_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 jv_bf16x2 __attribute__((ext_vector_type(2)));
+struct Split3 { unsigned h, m, l; };
+__device__ __forceinline__ Split3 split3_pair(const float x0, const float x1) {
+  unsigned h, m, l;
+  const jv_f32x2 x = {x0, x1};
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, jv_bf16x2));
+  const jv_f32x2 hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+  const jv_f32x2 r = x - hf;
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, jv_bf16x2));
+  const jv_f32x2 mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r - mf, jv_bf16x2));
+  return {h, m, l};
+}
+
 }  // namespace jv
