@@ -11,6 +11,7 @@
 // one lane^32 exchange per reduction.  K/V tiles of 32 keys are shared by the workgroup's waves through
 // LDS (row stride 68 floats: conflict-free ds_read_b128) and register-prefetched one tile ahead.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "jv_common.h"
@@ -207,8 +208,8 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
   __shared__ __attribute__((aligned(16))) unsigned char ldsK[3 * 32 * AK_ROWB];
   __shared__ __attribute__((aligned(16))) unsigned char ldsV[3 * 64 * AV_ROWB];
   constexpr int NT = 64 * NW;
-  constexpr int NKL = (32 * 16) / NT;   // f32x4 pieces of K per thread per tile
-  constexpr int KPT = 32 / NW;          // keys of V per thread per tile (one d column each)
+  constexpr int NKL = (32 * 16 + NT - 1) / NT;   // f32x4 pieces of K per thread per tile (512 pieces over the workgroup)
+  constexpr int NVG = (8 + NW - 1) / NW;         // groups of 4 consecutive keys of V per thread per tile (8 groups over the waves)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, half = lane >> 5;
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
   float m_run = -INFINITY, l_run = 0.f;
 
   f32x4 pk[NKL];
-  float pv[KPT];
+  float pv[NVG][4];
   const int vd = tid & 63, vkg = tid >> 6;
   // Rows past the last valid key are clamped to it instead of branched around: their scores are masked to -inf below, so
   // P is exactly 0 there and whatever finite K/V values were staged do not matter.
@@ -271,13 +272,18 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
 #pragma unroll
     for (int i = 0; i < NKL; ++i) {
       const int idx = tid + i * NT;
-      const unsigned key = (unsigned)min(k0 + (idx >> 4), len - 1);
-      pk[i] = *reinterpret_cast<const f32x4*>(kbase + (key * uld + 4u * (idx & 15)));
+      if ((512 % NT) == 0 || idx < 512) {
+        const unsigned key = (unsigned)min(k0 + (idx >> 4), len - 1);
+        pk[i] = *reinterpret_cast<const f32x4*>(kbase + (key * uld + 4u * (idx & 15)));
+      }
     }
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-      const unsigned key = (unsigned)min(k0 + vkg * KPT + i, len - 1);
-      pv[i] = vbase[key * uld];
+    for (int j = 0; j < NVG; ++j) {
+      const int g = vkg + j * NW;
+      if ((8 % NW) == 0 || g < 8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pv[j][e] = vbase[(unsigned)min(k0 + 4 * g + e, len - 1) * uld];
+      }
     }
   };
 
@@ -297,6 +303,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
 #pragma unroll
     for (int i = 0; i < NKL; ++i) {
       const int idx = tid + i * NT;
+      if ((512 % NT) != 0 && idx >= 512) continue;
       const int key = idx >> 4, c4 = idx & 15;
       u32x2 hh, mm, ll;
       { const Split3 t_ = split3_pair(pk[i][0], pk[i][1]); hh[0] = t_.h; mm[0] = t_.m; ll[0] = t_.l; }
@@ -307,12 +314,14 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
       *reinterpret_cast<u32x2*>(dst + 64 * AK_ROWB) = ll;
     }
 #pragma unroll
-    for (int g = 0; g < KPT / 4; ++g) {         // 4 consecutive keys stay consecutive under the bit swap
-      const int key = vkg * KPT + 4 * g;
+    for (int j = 0; j < NVG; ++j) {             // 4 consecutive keys stay consecutive under the bit swap
+      const int g = vkg + j * NW;
+      if ((8 % NW) != 0 && g >= 8) continue;
+      const int key = 4 * g;
       const int pos = (key & 0x13) | ((key & 4) << 1) | ((key & 8) >> 1);
       u32x2 hh, mm, ll;
-      { const Split3 t_ = split3_pair(pv[4 * g], pv[4 * g + 1]); hh[0] = t_.h; mm[0] = t_.m; ll[0] = t_.l; }
-      { const Split3 t_ = split3_pair(pv[4 * g + 2], pv[4 * g + 3]); hh[1] = t_.h; mm[1] = t_.m; ll[1] = t_.l; }
+      { const Split3 t_ = split3_pair(pv[j][0], pv[j][1]); hh[0] = t_.h; mm[0] = t_.m; ll[0] = t_.l; }
+      { const Split3 t_ = split3_pair(pv[j][2], pv[j][3]); hh[1] = t_.h; mm[1] = t_.m; ll[1] = t_.l; }
       unsigned char* dst = ldsV + vd * AV_ROWB + pos * 2;
       *reinterpret_cast<u32x2*>(dst) = hh;
       *reinterpret_cast<u32x2*>(dst + 64 * AV_ROWB) = mm;
@@ -400,35 +409,50 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
   }
 }
 
+namespace {
+
+template <int NW>
+void launch_x6(const AttnArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL((attn64_x6_kernel<NW, (NW == 2 ? 2 : 3)>), dim3(cdiv(a.L, 32 * NW) * a.H * a.B), dim3(64 * NW), 0, st, a);
+}
+
+}  // namespace
+
 int attention64(const AttnArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.L <= 0) return JV_OK;
   if ((a.ld & 3) || (a.ldo & 3) || (a.k_off & 3) || (a.v_off & 3))
     return fail(JV_ERR_ARG, "attention64: strides/offsets must be multiples of 4 floats");
-  // 64-query workgroups waste least on T = 300 (5 x 64); 128-query ones halve K/V staging at T = 512
   static const bool fp32_path = getenv("JV_ATTN_FP32") != nullptr;
-  int waste2 = round_up(a.L, 64) - a.L, waste4 = round_up(a.L, 128) - a.L;
-  // bf16x6: staging (split + V transpose) is per thread, so the 4-wave workgroup is ~1.4x faster per query row
-  // (measured 110 vs 76 TFLOP/s): prefer it unless its padding costs more than that
-  if (!fp32_path && round_up(a.L, 128) * 10 <= round_up(a.L, 64) * 13) waste4 = -1;
-  static const int wpe = getenv("JV_ATTN_WPE") ? atoi(getenv("JV_ATTN_WPE")) : 2;
   if (const char* ab = tuning_env("JV_ABLATE")) const_cast<AttnArgs&>(a).ablate = atoi(ab);
   const bool prof = prof_on();
   if (prof) prof_begin(st);
-  if (waste4 <= waste2) {
-    if (fp32_path) hipLaunchKernelGGL((attn64_kernel<4>), dim3(cdiv(a.L, 128) * a.H * a.B), dim3(256), 0, st, a);
-    else if (wpe == 2) hipLaunchKernelGGL((attn64_x6_kernel<4, 2>), dim3(cdiv(a.L, 128) * a.H * a.B), dim3(256), 0, st, a);
-    else if (wpe == 4) hipLaunchKernelGGL((attn64_x6_kernel<4, 4>), dim3(cdiv(a.L, 128) * a.H * a.B), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn64_x6_kernel<4, 3>), dim3(cdiv(a.L, 128) * a.H * a.B), dim3(256), 0, st, a);
+  const char* name = "";
+  if (fp32_path) {
+    // 64-query workgroups waste least on T = 300 (5 x 64); 128-query ones halve K/V staging at T = 512
+    const int waste2 = round_up(a.L, 64) - a.L, waste4 = round_up(a.L, 128) - a.L;
+    if (waste4 <= waste2) hipLaunchKernelGGL((attn64_kernel<4>), dim3(cdiv(a.L, 128) * a.H * a.B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn64_kernel<2>), dim3(cdiv(a.L, 64) * a.H * a.B), dim3(128), 0, st, a);
+    name = waste4 <= waste2 ? "attn64<4 waves>" : "attn64<2 waves>";
   } else {
-    if (fp32_path) hipLaunchKernelGGL((attn64_kernel<2>), dim3(cdiv(a.L, 64) * a.H * a.B), dim3(128), 0, st, a);
-    else hipLaunchKernelGGL((attn64_x6_kernel<2, 2>), dim3(cdiv(a.L, 64) * a.H * a.B), dim3(128), 0, st, a);
+    // One wave per 32 queries; every workgroup stages (splits, transposes) the K/V tiles of its head itself, so larger
+    // workgroups repeat less staging -- but only wave counts that fill the CU's four SIMDs evenly pay (measured at
+    // T = 300: 5-wave workgroups 174 us against 110 us for 4-wave ones; T = 512: 8 waves 61 us, 4 waves 67 us).
+    int nw = a.L <= 64 ? 2 : (round_up(a.L, 256) == round_up(a.L, 128) ? 8 : 4);
+    if (const char* f = tuning_env("JV_ATTN_NW")) nw = atoi(f);
+    switch (nw) {
+      case 2: launch_x6<2>(a, st); break;
+      case 4: launch_x6<4>(a, st); break;
+      case 8: launch_x6<8>(a, st); break;
+      default: return fail(JV_ERR_ARG, "attention64: bad wave count");
+    }
+    static const char* const names[9] = {"", "", "attn64_x6<2 waves>", "attn64_x6<3 waves>", "attn64_x6<4 waves>", "attn64_x6<5 waves>",
+                                         "attn64_x6<6 waves>", "attn64_x6<7 waves>", "attn64_x6<8 waves>"};
+    name = names[nw];
   }
   if (prof) {
     // algorithmic (full-length) figure of SURVEY.md 8(d): QK^T + PV = 4*L*L*64 per head; q,k,v,o once
     const double bh = (double)a.B * a.H;
-    prof_end(st, fp32_path ? (waste4 <= waste2 ? "attn64<4 waves>" : "attn64<2 waves>")
-                           : (waste4 <= waste2 ? "attn64_x6<4 waves>" : "attn64_x6<2 waves>"),
-             4.0 * bh * a.L * a.L * 64.0, 4.0 * bh * a.L * 64.0 * 4.0);
+    prof_end(st, name, 4.0 * bh * a.L * a.L * 64.0, 4.0 * bh * a.L * 64.0 * 4.0);
   }
   JV_HIP(hipGetLastError());
   return JV_OK;
