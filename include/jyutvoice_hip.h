@@ -72,6 +72,12 @@ int jv_flow_estimator_step(jv_context* ctx, const float* x, const int32_t* lens,
  * configs/base.yaml:98) and all left chunks; 0 restores full attention.  Applies to the following estimator / solver
  * calls on this context. */
 int jv_flow_set_streaming(jv_context* ctx, int chunk_frames);
+/* jv_flow_set_graph: jv_cfm_solve replays one Euler step (step scalars -> estimator input -> estimator -> CFG update,
+ * flow_matching.py:230-265) as a captured hipGraph per (B, T, attention mode), on a private stream fenced against
+ * `stream` with events; the step reads (t, dt) through a device-side counter so one graph serves every step.  On by
+ * default (JV_NO_GRAPH=1 in the environment at jv_create, or on = 0 here, turns it off); the in-library profiler
+ * (jv_profile_enable) forces the eager path because it brackets every launch with events.  Results are identical. */
+int jv_flow_set_graph(jv_context* ctx, int on);
 /* jv_cfm_solve: CausalConditionalCFM.forward + ConditionalCFM.solve_euler (flow_matching.py:356-401, 215-265):
  * fixed noise prefix * temperature, cosine schedule, n_timesteps Euler steps with CFG rate 0.7.
  * mu, cond, mel: [B,80,T]; spks: [B,80]; lens: [B] int32 or NULL.  t_span_host: optional n_timesteps+1 host floats

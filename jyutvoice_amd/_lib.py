@@ -46,6 +46,7 @@ SIGNATURES = {
     "jv_finalize": (_i, [_p, _i, _p]),
     "jv_flow_estimator_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
     "jv_flow_set_streaming": (_i, [_p, _i]),
+    "jv_flow_set_graph": (_i, [_p, _i]),
     "jv_cfm_solve": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
     "jv_encoder_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
     "jv_length_regulate": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _p, _i, _p, _p, _p]),

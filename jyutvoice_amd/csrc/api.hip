@@ -70,6 +70,7 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   Context& c = ctx->c;
   c.device = device;
   c.max_batch = max_batch;
+  c.step_graphs = getenv("JV_NO_GRAPH") == nullptr;
   c.max_frames = max_frames;
   c.max_tokens = max_tokens;
   jv::build_registry(c);
@@ -157,6 +158,7 @@ int jv_finalize(jv_context* ctx, int model, void* stream) {
   CTX_GUARD(ctx);
   if (model != JV_MODEL_TTS && model != JV_MODEL_HIFT) return jv::fail(JV_ERR_ARG, "jv_finalize: unknown model id");
   if (ctx->c.ready[model]) return JV_OK;
+  if (model == JV_MODEL_TTS) jv::flow_graphs_drop(ctx->c);
   return jv::finalize_model(ctx->c, model, static_cast<hipStream_t>(stream));
 }
 
@@ -171,6 +173,13 @@ int jv_flow_set_streaming(jv_context* ctx, int chunk_frames) {
   if (!ctx) return jv::fail(JV_ERR_ARG, "null context");
   if (chunk_frames < 0) return jv::fail(JV_ERR_ARG, "jv_flow_set_streaming: chunk must be >= 0");
   ctx->c.attn_chunk = chunk_frames;
+  return JV_OK;
+}
+
+int jv_flow_set_graph(jv_context* ctx, int on) {
+  if (!ctx) return jv::fail(JV_ERR_ARG, "null context");
+  ctx->c.step_graphs = on != 0;
+  if (!on) jv::flow_graphs_drop(ctx->c);
   return JV_OK;
 }
 

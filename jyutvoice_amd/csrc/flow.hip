@@ -31,6 +31,16 @@ struct FlowWs {
   int* row_sample = nullptr;
   int* lens2 = nullptr;     // [2*maxB]
   int max_steps = 1024;
+  // One Euler step (step scalars -> input assembly -> estimator -> CFG update) captured as a hipGraph per (B, T,
+  // attention mode): the step reads its (t, dt) through a device-side counter, so one executable graph replays for
+  // every step of every solve of that geometry.  Replayed on a private stream (the caller's may be the legacy
+  // default stream, which cannot be captured), fenced against the caller's stream with events.
+  int* step_ctr = nullptr;
+  float *t_cur = nullptr, *dt_cur = nullptr;
+  struct StepGraph { int B, T, chunk; hipGraph_t graph; hipGraphExec_t exec; };
+  std::vector<StepGraph> graphs;
+  hipStream_t gstream = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
 };
 
 static long flow_rows(int B2, int T) { return (long)FLOW_G + (long)B2 * (T + FLOW_GAP); }
@@ -66,10 +76,34 @@ int flow_ws_create(Context& c) {
   JV_TRY(ws_alloc(c, R, reinterpret_cast<void**>(&w->rowmask)));
   JV_TRY(ws_alloc(c, R * sizeof(int), reinterpret_cast<void**>(&w->row_sample)));
   JV_TRY(ws_alloc(c, (size_t)B2 * sizeof(int), reinterpret_cast<void**>(&w->lens2)));
+  JV_TRY(ws_alloc(c, sizeof(int), reinterpret_cast<void**>(&w->step_ctr)));
+  JV_TRY(F(&w->t_cur, 1));
+  JV_TRY(F(&w->dt_cur, 1));
+  JV_HIP(hipStreamCreateWithFlags(&w->gstream, hipStreamNonBlocking));
+  JV_HIP(hipEventCreateWithFlags(&w->ev_in, hipEventDisableTiming));
+  JV_HIP(hipEventCreateWithFlags(&w->ev_out, hipEventDisableTiming));
   return JV_OK;
 }
 
+void flow_graphs_drop(Context& c) {
+  if (!c.flow) return;
+  for (auto& e : c.flow->graphs) {
+    (void)hipGraphExecDestroy(e.exec);
+    (void)hipGraphDestroy(e.graph);
+  }
+  c.flow->graphs.clear();
+}
+
 namespace {
+
+// (t, dt) of the step the device-side counter points at, then advance it: the only step-dependent state of a solve
+__global__ void step_advance_kernel(const float* __restrict__ t_table, const float* __restrict__ dt_table, int* ctr,
+                                    float* t_cur, float* dt_cur) {
+  const int i = *ctr;
+  *t_cur = t_table[i];
+  *dt_cur = dt_table[i];
+  *ctr = i + 1;
+}
 
 struct Geo {
   int B2, T, S;
@@ -273,11 +307,59 @@ int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spk
   // z = rand_noise[:, :, :T] * temperature, the same prefix for every utterance (flow_matching.py:385)
   JV_TRY(cf_to_rows(c.noise, 0, NOISE_FRAMES, B, 80, T, w.x, 80, 0, FLOW_G, g.S, temperature, nullptr, st));
 
-  for (int s = 0; s < n_timesteps; ++s) {
-    JV_TRY(assemble_xin(w.x, w.mu, spks, w.cond, w.xin, B, FLOW_G, g.S, T, g.M, st));
-    g.t_ptr = w.t_table + s;   // the same t for all 2B rows (stride 0)
-    JV_TRY(estimator_body(c, g, st));
-    JV_TRY(euler_cfg(w.x, w.d, B, FLOW_G, g.S, T, w.dt_table, s, 0.7f, st));
+  JV_HIP(hipMemsetAsync(w.step_ctr, 0, sizeof(int), st));
+  JV_HIP(hipMemcpyAsync(w.spks, spks, sizeof(float) * 80 * B, hipMemcpyDeviceToDevice, st));
+  g.t_ptr = w.t_cur;   // the same t for all 2B rows (stride 0)
+  auto euler_step = [&](hipStream_t s) -> int {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, w.t_table, w.dt_table, w.step_ctr, w.t_cur, w.dt_cur);
+    JV_TRY(assemble_xin(w.x, w.mu, w.spks, w.cond, w.xin, B, FLOW_G, g.S, T, g.M, s));
+    JV_TRY(estimator_body(c, g, s));
+    return euler_cfg(w.x, w.d, B, FLOW_G, g.S, T, w.dt_cur, 0, 0.7f, s);
+  };
+  // The in-library profiler brackets every launch with events, which a capture would turn into graph nodes: eager then.
+  const bool use_graph = c.step_graphs && !prof_on() && n_timesteps > 1;
+  if (!use_graph) {
+    for (int s = 0; s < n_timesteps; ++s) JV_TRY(euler_step(st));
+  } else {
+    FlowWs::StepGraph* sg = nullptr;
+    for (auto& e : w.graphs)
+      if (e.B == B && e.T == T && e.chunk == c.attn_chunk) sg = &e;
+    int first = 0;
+    if (!sg) {
+      // first solve of this geometry: step 0 runs eagerly (it also performs the one-time kernel attribute setup),
+      // step 1 is captured; it does not execute during capture, so the replay loop starts from it
+      JV_TRY(euler_step(st));
+      first = 1;
+      JV_HIP(hipEventRecord(w.ev_in, st));
+      JV_HIP(hipStreamWaitEvent(w.gstream, w.ev_in, 0));
+      JV_HIP(hipStreamBeginCapture(w.gstream, hipStreamCaptureModeThreadLocal));
+      const int rc = euler_step(w.gstream);
+      hipGraph_t graph = nullptr;
+      const hipError_t ce = hipStreamEndCapture(w.gstream, &graph);
+      if (rc != JV_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      if (ce != hipSuccess || !graph) return fail(JV_ERR_HIP, "cfm_solve: stream capture of the Euler step failed");
+      hipGraphExec_t exec = nullptr;
+      if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        return fail(JV_ERR_HIP, "cfm_solve: hipGraphInstantiate failed");
+      }
+      if (w.graphs.size() >= 16) {   // bounded cache: drop the oldest geometry
+        (void)hipGraphExecDestroy(w.graphs.front().exec);
+        (void)hipGraphDestroy(w.graphs.front().graph);
+        w.graphs.erase(w.graphs.begin());
+      }
+      w.graphs.push_back({B, T, c.attn_chunk, graph, exec});
+      sg = &w.graphs.back();
+    } else {
+      JV_HIP(hipEventRecord(w.ev_in, st));
+      JV_HIP(hipStreamWaitEvent(w.gstream, w.ev_in, 0));
+    }
+    for (int s = first; s < n_timesteps; ++s) JV_HIP(hipGraphLaunch(sg->exec, w.gstream));
+    JV_HIP(hipEventRecord(w.ev_out, w.gstream));
+    JV_HIP(hipStreamWaitEvent(st, w.ev_out, 0));
   }
   return rows_to_cf(w.x, 80, 0, FLOW_G, g.S, mel, 80L * T, B, 80, T, lens_dev ? w.lens2 : nullptr, st);
 }
@@ -286,6 +368,12 @@ int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spk
 
 namespace jv {
 void flow_ws_destroy(Context& c) {
+  if (c.flow) {
+    flow_graphs_drop(c);
+    if (c.flow->gstream) (void)hipStreamDestroy(c.flow->gstream);
+    if (c.flow->ev_in) (void)hipEventDestroy(c.flow->ev_in);
+    if (c.flow->ev_out) (void)hipEventDestroy(c.flow->ev_out);
+  }
   delete c.flow;
   c.flow = nullptr;
 }

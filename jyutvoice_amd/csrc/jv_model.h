@@ -98,6 +98,7 @@ struct Context {
   HiftW hift;
   float* noise = nullptr;        // [80][15000] fixed CFM noise (device), supplied by the host
   bool noise_loaded = false;
+  bool step_graphs = true;       // replay the Euler step as a captured hipGraph (jv_flow_set_graph; off under the profiler)
   int attn_chunk = 0;            // > 0: streaming (chunk-causal) estimator attention, in frames (jv_flow_set_streaming)
   // workspace
   std::vector<void*> ws_allocs;
@@ -116,6 +117,7 @@ int ws_alloc(Context& c, size_t bytes, void** out);
 
 // flow.hip
 int flow_ws_create(Context& c);
+void flow_graphs_drop(Context& c);   // forget captured Euler-step graphs (weights or workspace pointers changed)
 int flow_estimator(Context& c, const float* x, const int* lens_dev, const float* mu, const float* t_dev, const float* spks,
                    const float* cond, int B2, int T, float* out, hipStream_t st);
 int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spks, const float* cond, int B, int T,

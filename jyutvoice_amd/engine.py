@@ -103,6 +103,10 @@ class Engine:
         """chunk-causal estimator attention (the reference's streaming=True); 0 = full attention"""
         check(self.lib.jv_flow_set_streaming(self._h, int(chunk_frames)))
 
+    def set_step_graph(self, on: bool = True):
+        """replay the Euler step of cfm_solve as a captured hipGraph (default on; same results as the eager path)"""
+        check(self.lib.jv_flow_set_graph(self._h, 1 if on else 0))
+
     def flow_estimator(self, x, mask_lens, mu, t, spks, cond):
         """[B2,80,T] tensors on the device; mask_lens int32 [B2] or None."""
         B2, _, T = x.shape

@@ -120,3 +120,34 @@ def test_streaming_chunk_causal_golden(eng, tts_sd):
         eng.set_streaming(0)
     full = eng.flow_estimator(g["x"], lens, g["mu"], g["t"], g["spks"], g["cond"])
     assert md(full, g["out"]) > 1e-2       # the mask really changes the result
+
+
+def test_step_graph_equals_eager(eng):
+    """the hipGraph-captured Euler step (jv_flow_set_graph) replays bit-identically to eager launches:
+    first solve (capture), cached replays, another step count on the same geometry, ragged lengths, streaming mask"""
+    g = torch.Generator().manual_seed(11)
+    B, T = 2, 77
+    lens = torch.tensor([77, 40], dtype=torch.int32)
+    mask = (torch.arange(T)[None] < lens[:, None]).unsqueeze(1).float()
+    mu = torch.randn(B, 80, T, generator=g) * mask
+    spks = torch.randn(B, 80, generator=g)
+    cond = torch.zeros(B, 80, T)
+    try:
+        eng.set_step_graph(False)
+        eager = {n: eng.cfm_solve(mu, lens, spks, cond, n, 1.0).cpu() for n in (1, 2, 5)}
+        eng.set_streaming(25)
+        eager_s = eng.cfm_solve(mu, lens, spks, cond, 3, 1.0).cpu()
+        eng.set_streaming(0)
+        eng.set_step_graph(True)
+        for n in (5, 2, 1, 5):                        # capture on the first, replay on the rest
+            assert torch.equal(eng.cfm_solve(mu, lens, spks, cond, n, 1.0).cpu(), eager[n]), n
+        spks2 = torch.randn(B, 80, generator=g)       # new operand values through the same cached graph
+        a = eng.cfm_solve(mu, lens, spks2, cond, 3, 0.7).cpu()
+        eng.set_step_graph(False)
+        assert torch.equal(a, eng.cfm_solve(mu, lens, spks2, cond, 3, 0.7).cpu())
+        eng.set_step_graph(True)
+        eng.set_streaming(25)
+        assert torch.equal(eng.cfm_solve(mu, lens, spks, cond, 3, 1.0).cpu(), eager_s)
+    finally:
+        eng.set_streaming(0)
+        eng.set_step_graph(True)
