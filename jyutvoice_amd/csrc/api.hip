@@ -70,7 +70,7 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   Context& c = ctx->c;
   c.device = device;
   c.max_batch = max_batch;
-  c.step_graphs = getenv("JV_NO_GRAPH") == nullptr;
+  c.step_graphs = getenv("JV_STEP_GRAPH") != nullptr;
   c.max_frames = max_frames;
   c.max_tokens = max_tokens;
   jv::build_registry(c);

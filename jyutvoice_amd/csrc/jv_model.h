@@ -98,7 +98,7 @@ struct Context {
   HiftW hift;
   float* noise = nullptr;        // [80][15000] fixed CFM noise (device), supplied by the host
   bool noise_loaded = false;
-  bool step_graphs = true;       // replay the Euler step as a captured hipGraph (jv_flow_set_graph; off under the profiler)
+  bool step_graphs = false;      // replay the Euler step as a captured hipGraph (jv_flow_set_graph; never under the profiler)
   int attn_chunk = 0;            // > 0: streaming (chunk-causal) estimator attention, in frames (jv_flow_set_streaming)
   // workspace
   std::vector<void*> ws_allocs;

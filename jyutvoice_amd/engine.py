@@ -104,7 +104,7 @@ class Engine:
         check(self.lib.jv_flow_set_streaming(self._h, int(chunk_frames)))
 
     def set_step_graph(self, on: bool = True):
-        """replay the Euler step of cfm_solve as a captured hipGraph (default on; same results as the eager path)"""
+        """replay the Euler step of cfm_solve as a captured hipGraph (default off: measured no faster; same results)"""
         check(self.lib.jv_flow_set_graph(self._h, 1 if on else 0))
 
     def flow_estimator(self, x, mask_lens, mu, t, spks, cond):

@@ -150,4 +150,4 @@ def test_step_graph_equals_eager(eng):
         assert torch.equal(eng.cfm_solve(mu, lens, spks, cond, 3, 1.0).cpu(), eager_s)
     finally:
         eng.set_streaming(0)
-        eng.set_step_graph(True)
+        eng.set_step_graph(False)
