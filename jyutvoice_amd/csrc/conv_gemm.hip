@@ -125,10 +125,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p, co
       if (i < na && r < win) {
         f32x4 v = pa[i];
         if (PRO == PRO_SNAKE) {
+          const f32x4 arg = v * al;
+          const bool big = fabsf(arg[0]) > 32768.f || fabsf(arg[1]) > 32768.f || fabsf(arg[2]) > 32768.f ||
+                           fabsf(arg[3]) > 32768.f;      // false for NaN, which sin2_small propagates
+          if (snake_args_small(big)) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float sn = sinf(v[e] * al[e]);
-            v[e] = v[e] + (1.0f / (al[e] + 1e-9f)) * (sn * sn);
+            for (int e = 0; e < 4; ++e) v[e] = v[e] + (1.0f / (al[e] + 1e-9f)) * sin2_small(arg[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float sn = sinf(arg[e]);
+              v[e] = v[e] + (1.0f / (al[e] + 1e-9f)) * (sn * sn);
+            }
           }
         } else if (PRO == PRO_LRELU) {
 #pragma unroll

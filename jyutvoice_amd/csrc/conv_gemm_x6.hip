@@ -128,11 +128,24 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
           for (int e = 0; e < 8; ++e) x[e] = pa[i][2 * g + (e >> 2)][e & 3];
           if (PRO == PRO_SNAKE) {
             const float* al = p.pro_alpha + c0 + 16 * khalf + 8 * g;
+            float arg[8], inv[8];
+            bool big = false;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const float a = al[e];
-              const float sn = sinf(x[e] * a);
-              x[e] = x[e] + (1.0f / (a + 1e-9f)) * (sn * sn);
+              arg[e] = x[e] * a;
+              inv[e] = 1.0f / (a + 1e-9f);
+              big = big || fabsf(arg[e]) > 32768.f;      // false for NaN, which sin2_small propagates
+            }
+            if (snake_args_small(big)) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] = x[e] + inv[e] * sin2_small(arg[e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float sn = sinf(arg[e]);
+                x[e] = x[e] + inv[e] * (sn * sn);
+              }
             }
           } else if (PRO == PRO_LRELU) {
 #pragma unroll

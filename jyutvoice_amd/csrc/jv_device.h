@@ -24,6 +24,27 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
+// sin^2(a) for the Snake activation x + sin^2(alpha x) / alpha (jyutvoice/hifigan/generator.py Snake).  sinf() costs ~130
+// VALU instructions per value on gfx950 (its Payne-Hanek path is compiled in line), which made the Snake-prologue
+// convolutions VALU-bound.  Here: a = k pi + r with a two-constant Cody-Waite reduction (exact products through fma; the
+// sign of sin(r) is irrelevant once squared), then an odd degree-11 polynomial on [-pi/2, pi/2].  |a| <= 2^15: absolute
+// error <= 2.3e-7 against fp64 (a correctly rounded sinf squared: 0.9e-7).  Callers route larger or non-finite arguments
+// to sinf (snake_args_small).
+__device__ __forceinline__ float sin2_small(const float a) {
+  const float k = rintf(a * 0.31830988618379067154f);
+  float r = fmaf(-k, 3.1415927410125732f, a);
+  r = fmaf(-k, -8.742277657347586e-08f, r);
+  const float u = r * r;
+  float q = fmaf(-4.054625790672617e-08f, u, 2.843463789758971e-06f);
+  q = fmaf(q, u, -1.9857272855006158e-04f);
+  q = fmaf(q, u, 8.333439007401466e-03f);
+  q = fmaf(q, u, -1.666666865348816e-01f);
+  const float sn = fmaf(r * u, q, r);
+  return sn * sn;
+}
+// wave-uniform: true when every lane's argument is in sin2_small's range (NaN compares false and propagates through it)
+__device__ __forceinline__ bool snake_args_small(const bool lane_has_big) { return __builtin_amdgcn_ballot_w64(lane_has_big) == 0; }
+
 // bf16x3 split of two fp32 values at once: x ~= h + m + l to 24 bits (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m),
 // round to nearest even).  Returns each plane as one dword holding the pair (element 0 in the low half), the form
 // v_cvt_pk_bf16_f32 produces and the MFMA operands consume.

@@ -107,6 +107,27 @@ def test_dilated_conv_snake_residual(dev, k, dil, C):
     assert float((want - want2).abs().max()) < 1e-9
 
 
+def test_snake_argument_ranges(dev):
+    """Snake's sin^2 takes the short reduction for |alpha x| <= 2^15 and sinf beyond (csrc/jv_device.h sin2_small): both
+    ranges, and rows mixing them, against fp64 sin of the same fp32 product"""
+    from jyutvoice_amd.engine import op_conv_gemm
+    g = torch.Generator().manual_seed(77)
+    rows, C = 300, 64
+    A = torch.randn(rows, C, generator=g)
+    A[:100] *= 3000.0                       # |alpha x| up to ~1e4: still the short path
+    A[100:200] *= 2.0e5                     # far beyond 2^15: sinf path
+    A[200:, ::7] *= 1.0e5                   # mixed inside one 8-value group
+    w = torch.zeros(C, C, 1)
+    w[:, :, 0] = torch.eye(C)               # identity 1x1 conv: the output is the prologue itself
+    alpha = 1 + 0.1 * torch.randn(C, generator=g).abs()
+    out = op_conv_gemm(A.to(dev), pack_conv(w).to(dev), torch.zeros(C).to(dev), ntaps=1, tap_row0=0, prologue="snake",
+                       alpha=alpha.to(dev)).double().cpu()
+    arg = (A * alpha).double()              # the fp32 product both implementations take the sine of
+    want = A.double() + (1.0 / (alpha + 1e-9)).double() * torch.sin(arg) ** 2
+    err = (out - want).abs()
+    assert float((err / want.abs().clamp_min(1.0)).max()) < 1e-6
+
+
 def test_lrelu_prologue(dev):
     from jyutvoice_amd.engine import op_conv_gemm
     g = torch.Generator().manual_seed(5)
