@@ -306,11 +306,16 @@ int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
 template <int BM, int BN, int WM, int WN, int PRO, int EPI>
 int x6_launch2(const ConvGemmArgs& a, hipStream_t st) {
   const int win = BM + (a.ntaps - 1) * a.tap_dil;
-  if constexpr (BM == 128) {
-    if (win > 128) return x6_launch3<BM, BN, WM, WN, PRO, EPI, 2>(a, st);
+  if constexpr (BM > 128) {
+    if (win > 256) return fail(JV_ERR_ARG, "conv_gemm_x6: window too tall for this tile variant");
+    return x6_launch3<BM, BN, WM, WN, PRO, EPI, 2>(a, st);
+  } else {
+    if constexpr (BM == 128) {
+      if (win > 128) return x6_launch3<BM, BN, WM, WN, PRO, EPI, 2>(a, st);
+    }
+    if (win > 128) return fail(JV_ERR_ARG, "conv_gemm_x6: window too tall for this tile variant");
+    return x6_launch3<BM, BN, WM, WN, PRO, EPI, 1>(a, st);
   }
-  if (win > 128) return fail(JV_ERR_ARG, "conv_gemm_x6: window too tall for this tile variant");
-  return x6_launch3<BM, BN, WM, WN, PRO, EPI, 1>(a, st);
 }
 
 template <int BM, int BN, int WM, int WN, int PRO>
@@ -320,7 +325,8 @@ int x6_launch1(const ConvGemmArgs& a, hipStream_t st) {
   if (lean && a.act == ACT_NONE)
     return a.res1 ? x6_launch2<BM, BN, WM, WN, PRO, 2>(a, st) : x6_launch2<BM, BN, WM, WN, PRO, 0>(a, st);
   if (lean && a.act == ACT_GELU && PRO == PRO_NONE && !a.res1) return x6_launch2<BM, BN, WM, WN, PRO_NONE, 1>(a, st);
-  return x6_launch2<BM, BN, WM, WN, PRO, 4>(a, st);
+  if constexpr (WM > 64) return fail(JV_ERR_ARG, "conv_gemm_x6: this tile variant has no generic epilogue");
+  else return x6_launch2<BM, BN, WM, WN, PRO, 4>(a, st);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -338,27 +344,38 @@ int x6_launch(const ConvGemmArgs& a, hipStream_t st) {
 // Same contract as conv_gemm() (argument checks done there); requires a.W3.
 int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st) {
   const int span = (a.ntaps - 1) * a.tap_dil;
-  struct Cand { int bm, bn; double eff; size_t lds; };
-  // measured on the estimator shapes (tools/gemm_bench.py): the big tile amortises staging and barriers best
-  const Cand cands[3] = {{128, 128, 1.0, x6_lds_bytes<128, 128>(a)}, {64, 128, 0.8, x6_lds_bytes<64, 128>(a)},
-                         {64, 64, 0.8, x6_lds_bytes<64, 64>(a)}};
+  struct Cand { int bm, bn; double eff; size_t lds; int max_win; };
+  // measured on the estimator shapes (tools/gemm_bench.py): the big tile amortises staging and barriers best.  The
+  // 160-row tile (each wave 160 x 32) exists for the workgroup-round arithmetic: M = 19.5K rows x N = 1024 is 2.4 rounds
+  // of 128 x 128 tiles over 512 slots (3 to wait for) but 1.9 rounds of 160 x 128 ones; it has no generic epilogue.
+  const bool lean = !(a.N & 3) && !(a.ldo & 3) && (!a.res1 || !(a.ldr1 & 3)) && !a.res2 && !a.rowvec && !a.rowmask_out &&
+                    !a.accumulate && a.out_scale == 1.f && (a.act == ACT_NONE || (a.act == ACT_GELU && a.pro == PRO_NONE && !a.res1));
+  const Cand cands[4] = {{128, 128, 1.0, x6_lds_bytes<128, 128>(a), 256}, {64, 128, 0.8, x6_lds_bytes<64, 128>(a), 128},
+                         {64, 64, 0.8, x6_lds_bytes<64, 64>(a), 128}, {160, 128, 0.97, x6_lds_bytes<160, 128>(a), 256}};
   int best = -1;
   double best_cost = 0;
   for (int i = 0; i < 3; ++i) {
-    if (cands[i].bm + span > (i == 0 ? 256 : 128)) continue;
+    if (cands[i].bm + span > cands[i].max_win) continue;
     if (cands[i].lds > 80 * 1024 && i < 2) continue;
     const long tiles = (long)cdiv(a.M, cands[i].bm) * cdiv(a.N, cands[i].bn);
     const double cost = (double)cdivl(tiles, 256) * cands[i].bm * cands[i].bn / cands[i].eff;
     if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
   }
+  if (best == 0 && lean && cands[3].bm + span <= cands[3].max_win && !getenv("JV_NO_T160")) {
+    // both run two workgroups per CU: rounds of 512 resident tiles x rows per tile
+    const long r128 = cdivl((long)cdiv(a.M, 128) * cdiv(a.N, 128), 512) * 128;
+    const long r160 = cdivl((long)cdiv(a.M, 160) * cdiv(a.N, 128), 512) * 160;
+    if ((double)r160 / cands[3].eff < (double)r128) best = 3;
+  }
   if (const char* force = getenv("JV_TILE")) {
     const int f = atoi(force);
-    if (f >= 0 && f <= 2 && cands[f].bm + span <= (f == 0 ? 256 : 128)) best = f;
+    if (f >= 0 && f <= 3 && cands[f].bm + span <= cands[f].max_win && (f != 3 || lean)) best = f;
   }
   switch (best) {
     case 0: return x6_launch<128, 128, 64, 64>(a, st);
     case 1: return x6_launch<64, 128, 32, 64>(a, st);
     case 2: return x6_launch<64, 64, 32, 32>(a, st);
+    case 3: return x6_launch<160, 128, 160, 32>(a, st);
     default: return fail(JV_ERR_ARG, "conv_gemm_x6: no tile variant fits this tap span");
   }
 }

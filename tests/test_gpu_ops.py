@@ -204,3 +204,24 @@ def test_x6_gelu_and_generic_epilogues(dev, x6):
     test_activations(dev, "gelu")
     test_activations(dev, "elu")
     test_lrelu_prologue(dev)
+
+
+@pytest.mark.parametrize("tile", ["0", "1", "2", "3"])
+def test_x6_every_tile_variant(dev, x6, monkeypatch, tile):
+    """each tile shape of the bf16x6 kernel (128x128, 64x128, 64x64, 160x128) on one problem with ragged edges in M and N,
+    plain / GELU / residual epilogues and a 3-tap causal window"""
+    from jyutvoice_amd.engine import op_conv_gemm
+    monkeypatch.setenv("JV_TILE", tile)
+    g = torch.Generator().manual_seed(40 + int(tile))
+    M, K, N = 1000, 256, 392
+    A = torch.randn(M + 8, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    want = A[:M].double() @ W.double().T + b.double()
+    assert rel_err(op_conv_gemm(A.to(dev), W.to(dev), b.to(dev), M=M), want) < 2e-6
+    assert rel_err(op_conv_gemm(A.to(dev), W.to(dev), b.to(dev), M=M, act="gelu"), F.gelu(want)) < 2e-6
+    assert rel_err(op_conv_gemm(A.to(dev), W.to(dev), b.to(dev), M=M, res=res.to(dev)), want + res.double()) < 2e-6
+    w3 = torch.randn(N, K, 3, generator=g) / math.sqrt(3 * K)
+    out = op_conv_gemm(A.to(dev), pack_conv(w3).to(dev), b.to(dev), ntaps=3, tap_row0=-2, M=M)
+    assert rel_err(out, conv_rows_ref(A, w3, b, -2, 1)[:M]) < 2e-6
