@@ -30,6 +30,22 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA
 HBM_PEAK_GBS = 8000.0
 
 
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/profile.sh: rocprofv3 --pmc FETCH_SIZE, doubled
+    as MI355X_MICROARCH.md prescribes for gfx950, and --pmc WRITE_SIZE; counters cannot be read from inside this process).
+    Only quoted for the workload those passes ran (the default C3 shape); null otherwise."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_pmc_traffic.json")
+    if (args.batch, args.tokens, args.timesteps) != (32, 150, 10) or not os.path.exists(path):
+        return {}
+    with open(path) as fh:
+        d = json.load(fh)
+    k = d["kernels"].get(kernel)
+    if not k or "fetch_bytes" not in k or "write_bytes" not in k:
+        return {}
+    return {"traffic": k["fetch_bytes"] + k["write_bytes"], "traffic_fetch": k["fetch_bytes"], "traffic_write": k["write_bytes"],
+            "traffic_source": "profiles/r01_final_pmc_traffic.json <- " + d["source"]}
+
+
 def kernel_peak(name: str):
     """(peak TFLOP/s of algorithmic fp32 work, description) for a profiled kernel family"""
     if name.startswith("conv_gemm_x6") or name.startswith("attn64_x6"):
@@ -192,7 +208,7 @@ def main():
             peak, precision = kernel_peak(name)
             out["roofline"] = {
                 "kernel": name, "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(tf / peak, 4), "traffic": None,
+                "frac": round(tf / peak, 4), "traffic": None, "traffic_unit": "bytes per launch (fetch + write)",
                 "launches": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                 "alg_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
                 "alg_hbm_gbs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
@@ -200,6 +216,7 @@ def main():
                 "measured": "HIP events on the launch stream around every launch, inside the timed region (jv_profile_*)",
                 "precision": precision,
             }
+            out["roofline"].update(pmc_traffic(name, args))
             out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
                                   "frac_of_peak": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / kernel_peak(k)[0], 3) if v["ms"] > 0 else 0.0}

@@ -22,7 +22,7 @@ def short(name):
         pro = {"0": "", "1": ",snake", "2": ",lrelu"}[m.group(3)]
         epi = {"0": "", "1": ",gelu", "2": ",res", "4": ",generic"}.get(m.group(4), "")
         return f"conv_gemm<{m.group(1)}x{m.group(2)}{pro}{epi}>"
-    m = re.search(r"attn64_x6_kernel<(\d)>", name)
+    m = re.search(r"attn64_x6_kernel<(\d)", name)
     if m:
         return f"attn64_x6<{m.group(1)} waves>"
     m = re.search(r"conv_gemm_kernelILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+ELb([01])ELi(\d)", name)
@@ -53,6 +53,7 @@ if stats:
               f"{float(r['AverageNs']) / 1e3:.2f} | {100 * float(r['TotalDurationNs']) / tot:.1f} |")
     print(f"\ntotal kernel time {tot / 1e6:.1f} ms\n")
 
+traffic = defaultdict(dict)
 for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     files = glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True)
     if not files:
@@ -71,3 +72,12 @@ for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
         print(f"| {k} | {n} | {mult * v * 1024 / n / 1e6:.2f} |")
     print()
+    for k, (n, v) in agg.items():
+        traffic[k]["fetch_bytes" if counter == "FETCH_SIZE" else "write_bytes"] = round(mult * v * 1024 / n)
+
+if traffic:   # per-launch HBM bytes by kernel, read back by bench.py for roofline.traffic
+    import json
+    with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
+        json.dump({"source": f"tools/profile.sh {os.path.basename(out)}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE, "
+                             "separate passes over bench.py --steps 1, bytes per launch",
+                   "kernels": traffic}, fh, indent=1, sort_keys=True)
