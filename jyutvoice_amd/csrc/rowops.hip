@@ -107,6 +107,8 @@ int layernorm_rows(const float* x, const float* add, float* out, const float* g,
   if (rows <= 0) return JV_OK;
   if (C & 3 || C > 1024) return fail(JV_ERR_ARG, "layernorm_rows: C must be a multiple of 4, <= 1024");
   const dim3 grid((unsigned)cdivl(rows, 4));
+  const bool prof = prof_on();
+  if (prof) prof_begin(st);
   if (C == 256 && !add && !rowmask_out && !relu)
     hipLaunchKernelGGL(layernorm256_kernel, dim3((unsigned)cdivl(rows, 16)), dim3(256), 0, st, x, out, g, b, eps, rows);
   else if (C <= 256)
@@ -115,6 +117,7 @@ int layernorm_rows(const float* x, const float* add, float* out, const float* g,
     hipLaunchKernelGGL((layernorm_rows_kernel<3>), grid, dim3(256), 0, st, x, add, out, g, b, eps, rows, C, rowmask_out, relu);
   else
     hipLaunchKernelGGL((layernorm_rows_kernel<4>), grid, dim3(256), 0, st, x, add, out, g, b, eps, rows, C, rowmask_out, relu);
+  if (prof) prof_end(st, "layernorm", 0.0, 4.0 * rows * C * (add ? 3 : 2));   // HBM-bound: rows read (+ add) and written once
   JV_HIP(hipGetLastError());
   return JV_OK;
 }
@@ -181,12 +184,15 @@ int ln_epilogue_rows(float* x, const float* g, const float* b, float eps, long r
   if ((C & 3) || C > 1024 || (rowvec && (rowvec_ld & 3)) || (res && (ldr & 3)))
     return fail(JV_ERR_ARG, "ln_epilogue_rows: C, rowvec_ld and ldr must be multiples of 4 (C <= 1024)");
   const dim3 grid((unsigned)cdivl(rows, 4));
+  const bool prof = prof_on();
+  if (prof) prof_begin(st);
   if (C <= 256)
     hipLaunchKernelGGL((ln_epilogue_kernel<1>), grid, dim3(256), 0, st, x, g, b, eps, rows, C, act, rowmask, rowvec, row_sample,
                        rowvec_ld, res, ldr, scale);
   else
     hipLaunchKernelGGL((ln_epilogue_kernel<4>), grid, dim3(256), 0, st, x, g, b, eps, rows, C, act, rowmask, rowvec, row_sample,
                        rowvec_ld, res, ldr, scale);
+  if (prof) prof_end(st, "ln_epilogue", 0.0, 4.0 * rows * C * (res ? 3 : 2));
   JV_HIP(hipGetLastError());
   return JV_OK;
 }
