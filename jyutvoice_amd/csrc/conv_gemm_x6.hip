@@ -350,8 +350,9 @@ int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st) {
   // of 128 x 128 tiles over 512 slots (3 to wait for) but 1.9 rounds of 160 x 128 ones; it has no generic epilogue.
   const bool lean = !(a.N & 3) && !(a.ldo & 3) && (!a.res1 || !(a.ldr1 & 3)) && !a.res2 && !a.rowvec && !a.rowmask_out &&
                     !a.accumulate && a.out_scale == 1.f && (a.act == ACT_NONE || (a.act == ACT_GELU && a.pro == PRO_NONE && !a.res1));
-  const Cand cands[4] = {{128, 128, 1.0, x6_lds_bytes<128, 128>(a), 256}, {64, 128, 0.8, x6_lds_bytes<64, 128>(a), 128},
-                         {64, 64, 0.8, x6_lds_bytes<64, 64>(a), 128}, {160, 128, 0.97, x6_lds_bytes<160, 128>(a), 256}};
+  const Cand cands[5] = {{128, 128, 1.0, x6_lds_bytes<128, 128>(a), 256}, {64, 128, 0.8, x6_lds_bytes<64, 128>(a), 128},
+                         {64, 64, 0.8, x6_lds_bytes<64, 64>(a), 128}, {160, 128, 0.97, x6_lds_bytes<160, 128>(a), 256},
+                         {128, 64, 0.9, x6_lds_bytes<128, 64>(a), 256}};
   int best = -1;
   double best_cost = 0;
   for (int i = 0; i < 3; ++i) {
@@ -361,6 +362,11 @@ int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st) {
     const double cost = (double)cdivl(tiles, 256) * cands[i].bm * cands[i].bn / cands[i].eff;
     if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
   }
+  // narrow outputs over very many rows (the vocoder's 64-channel stage, M ~ 1e6): a 128 x 64 tile (each wave 64 x 32) reads
+  // LDS 0.75 times per MFMA instead of once and stages each weight row for twice the rows
+  if (best == 2 && a.N <= 64 && a.M >= 128 * 512 && cands[4].bm + span <= cands[4].max_win && cands[4].lds <= 80 * 1024 &&
+      !getenv("JV_NO_T128x64"))
+    best = 4;
   if (best == 0 && lean && cands[3].bm + span <= cands[3].max_win && !getenv("JV_NO_T160")) {
     // both run two workgroups per CU: rounds of 512 resident tiles x rows per tile
     const long r128 = cdivl((long)cdiv(a.M, 128) * cdiv(a.N, 128), 512) * 128;
@@ -369,13 +375,14 @@ int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st) {
   }
   if (const char* force = getenv("JV_TILE")) {
     const int f = atoi(force);
-    if (f >= 0 && f <= 3 && cands[f].bm + span <= cands[f].max_win && (f != 3 || lean)) best = f;
+    if (f >= 0 && f <= 4 && cands[f].bm + span <= cands[f].max_win && (f != 3 || lean)) best = f;
   }
   switch (best) {
     case 0: return x6_launch<128, 128, 64, 64>(a, st);
     case 1: return x6_launch<64, 128, 32, 64>(a, st);
     case 2: return x6_launch<64, 64, 32, 32>(a, st);
     case 3: return x6_launch<160, 128, 160, 32>(a, st);
+    case 4: return x6_launch<128, 64, 64, 32>(a, st);
     default: return fail(JV_ERR_ARG, "conv_gemm_x6: no tile variant fits this tap span");
   }
 }

@@ -206,9 +206,9 @@ def test_x6_gelu_and_generic_epilogues(dev, x6):
     test_lrelu_prologue(dev)
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2", "3"])
+@pytest.mark.parametrize("tile", ["0", "1", "2", "3", "4"])
 def test_x6_every_tile_variant(dev, x6, monkeypatch, tile):
-    """each tile shape of the bf16x6 kernel (128x128, 64x128, 64x64, 160x128) on one problem with ragged edges in M and N,
+    """each tile shape of the bf16x6 kernel (128x128, 64x128, 64x64, 160x128, 128x64) on one problem with ragged edges in M and N,
     plain / GELU / residual epilogues and a 3-tap causal window"""
     from jyutvoice_amd.engine import op_conv_gemm
     monkeypatch.setenv("JV_TILE", tile)
