@@ -49,7 +49,11 @@ __device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& h, u32x4& m
 // The 64x64 plain variants are held to 96 registers so five workgroups fit a CU: the N = 256 GEMMs of the estimator
 // make 1220 such tiles, which then all run in one resident wave (1280 slots) instead of 1024 + a 20 % tail.
 // NA2: window rows staged per thread (rows tid>>1 + 128 i): 1 when the A window fits 128 rows, else 2
-template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2>
+// GL: the weight planes go global -> LDS by LDS-DMA (global_load_lds_dwordx4) into two alternating buffers, issued a whole
+// MFMA phase ahead, instead of through registers and ds_write_b128 between the two barriers of a step; both LDS images
+// are then unpadded 64-byte rows whose 16-byte slots are XOR-swizzled with (row >> 2) & 3 (for W on the SOURCE address:
+// the DMA writes lane-linear), which keeps every ds_read_b128 lane group on 64 distinct banks.  1-tap (Linear) shapes only.
+template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, bool GL = false>
 __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EPI != 4) ? 5 : 2) void conv_gemm_x6_kernel(const ConvGemmArgs p, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = WM / 32, NT = WN / 32;
@@ -77,8 +81,9 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
 
   const int ntaps = p.ntaps, dil = p.tap_dil;
   const int win = BM + (ntaps - 1) * dil;
-  unsigned char* const ldsA = reinterpret_cast<unsigned char*>(smem);            // [3][win][80 B]
-  unsigned char* const ldsW = ldsA + 3 * win * X6_ROWB;                          // [3][BN][80 B]
+  constexpr int ROWB = GL ? 64 : X6_ROWB;
+  unsigned char* const ldsA = reinterpret_cast<unsigned char*>(smem);            // [3][win][ROWB]
+  unsigned char* const ldsW = ldsA + 3 * win * ROWB;                             // [3][BN][80 B], or GL: [2][3][BN][64 B]
 
   unsigned avalid = 0;
 #pragma unroll
@@ -153,10 +158,11 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
           }
           u32x4 h, m, l;
           split3x8(x, h, m, l);
-          unsigned char* dst = ldsA + r * X6_ROWB + (16 * khalf + 8 * g) * 2;
+          unsigned char* dst = GL ? ldsA + r * 64 + (((2 * khalf + g) ^ ((r >> 2) & 3)) << 4)
+                                  : ldsA + r * X6_ROWB + (16 * khalf + 8 * g) * 2;
           *reinterpret_cast<u32x4*>(dst) = h;
-          *reinterpret_cast<u32x4*>(dst + win * X6_ROWB) = m;
-          *reinterpret_cast<u32x4*>(dst + 2 * win * X6_ROWB) = l;
+          *reinterpret_cast<u32x4*>(dst + win * ROWB) = m;
+          *reinterpret_cast<u32x4*>(dst + 2 * win * ROWB) = l;
         }
       }
     }
@@ -167,6 +173,25 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
       const int idx = tid + 256 * i;
       const int plane = idx / (BN * 4), rem = idx % (BN * 4);
       *reinterpret_cast<u32x4*>(ldsW + (plane * BN + (rem >> 2)) * X6_ROWB + (rem & 3) * 16) = pw[i];
+    }
+  };
+
+  // GL: 3 * BN / 16 one-KiB pieces (16 weight rows x 64 B of one plane) per step, dealt round-robin to the four waves
+  auto dma_W = [&](int c0, int buf) {
+    if constexpr (GL) {
+      constexpr int PIECES = 3 * BN / 16;
+#pragma unroll
+      for (int i = 0; i < PIECES / 4; ++i) {
+        const int pc = wave + 4 * i;
+        const int plane = pc / (BN / 16), g16 = pc % (BN / 16);
+        const int row = g16 * 16 + (lane >> 2);
+        const int kslot = (lane & 3) ^ ((row >> 2) & 3);
+        const int n = min(n0 + row, p.n_rows_w - 1);      // rows past the weight matrix feed columns that are never stored
+        const unsigned short* src = p.W3 + (long)plane * p.w3_plane + (long)n * p.ldw + c0 + 8 * kslot;
+        unsigned char* dst = ldsW + ((buf * 3 + plane) * BN + g16 * 16) * 64;      // wave-uniform; the DMA adds lane * 16
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
     }
   };
 
@@ -181,37 +206,41 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
   const int nchunks = p.Cin >> 5;
   const int nsteps = nchunks * ntaps;
   load_A(0);
-  load_W(0, 0);
+  if constexpr (GL) dma_W(0, 0);
+  else load_W(0, 0);
   if (JV_STAMP(p)) t_loop = __builtin_amdgcn_s_memtime();
   int c = 0, j = 0;
   for (int s = 0; s < nsteps; ++s) {
     if (!JV_ABLATE(p, 4)) __syncthreads();
     if (!JV_ABLATE(p, 2)) {
       if (j == 0) store_A(c * 32);
-      store_W();
+      if constexpr (!GL) store_W();
     }
-    if (!JV_ABLATE(p, 4)) __syncthreads();
+    if (!JV_ABLATE(p, 4)) __syncthreads();      // GL: its vmcnt(0) also retires this step's weight DMA, issued a phase ago
     int j2 = j + 1, c2 = c;
     if (j2 == ntaps) { j2 = 0; c2 = c + 1; }
     if (s + 1 < nsteps && !JV_ABLATE(p, 1)) {
       if (j2 == 0) load_A(c2 * 32);
-      load_W(j2, c2 * 32);
+      if constexpr (GL) dma_W(c2 * 32, (s + 1) & 1);      // that buffer was last read in step s - 1, before the barriers above
+      else load_W(j2, c2 * 32);
     }
-    const unsigned char* la = ldsA + (wm * WM + r32 + j * dil) * X6_ROWB + 16 * half;
-    const unsigned char* lw = ldsW + (wn * WN + r32) * X6_ROWB + 16 * half;
+    const unsigned char* la = ldsA + (wm * WM + r32 + j * dil) * ROWB + (GL ? 0 : 16 * half);
+    const unsigned char* lw = ldsW + (GL ? (s & 1) * 3 * BN * 64 : 0) + (wn * WN + r32) * ROWB + (GL ? 0 : 16 * half);
+    const int swz = (r32 >> 2) & 3;             // GL: WM, WN and the 32-row fragment steps are multiples of 16 rows
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {            // two k-steps of 16 per 32-channel chunk
       bf16x8 a[MT][3], b[NT][3];
+      const int koff = GL ? (((2 * ks + half) ^ swz) << 4) : 32 * ks;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-          a[mt][pl] = *reinterpret_cast<const bf16x8*>(la + (pl * win + mt * 32) * X6_ROWB + 32 * ks);
+          a[mt][pl] = *reinterpret_cast<const bf16x8*>(la + (pl * win + mt * 32) * ROWB + koff);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-          b[nt][pl] = *reinterpret_cast<const bf16x8*>(lw + (pl * BN + nt * 32) * X6_ROWB + 32 * ks);
+          b[nt][pl] = *reinterpret_cast<const bf16x8*>(lw + (pl * BN + nt * 32) * ROWB + koff);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -237,20 +266,20 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
 namespace {
 
 template <int BM, int BN>
-size_t x6_lds_bytes(const ConvGemmArgs& a) {
+size_t x6_lds_bytes(const ConvGemmArgs& a, bool gl = false) {
   const int win = BM + (a.ntaps - 1) * a.tap_dil;
-  return (size_t)3 * (win + BN) * X6_ROWB;
+  return gl ? (size_t)3 * (win + 2 * BN) * 64 : (size_t)3 * (win + BN) * X6_ROWB;
 }
 
-template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2>
+template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, bool GL = false>
 int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
   static bool raised = false;
   if (!raised) {
-    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2>),
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, GL>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     raised = true;
   }
-  size_t lds = x6_lds_bytes<BM, BN>(a);
+  size_t lds = x6_lds_bytes<BM, BN>(a, GL);
   const size_t need = (size_t)4 * 32 * (WN + 4) * sizeof(float);
   if (lds < need) lds = need;
   const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
@@ -266,7 +295,7 @@ int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, st);
-    hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2>), dim3(nwg), dim3(256), lds, st, b, tiles_n);
+    hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, GL>), dim3(nwg), dim3(256), lds, st, b, tiles_n);
     (void)hipEventRecord(e1, st);
     (void)hipStreamSynchronize(st);
     float ms = 0.f;
@@ -289,7 +318,7 @@ int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
     }
     return JV_OK;
   }
-  hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2>), dim3(tiles_m * tiles_n), dim3(256), lds, st, a, tiles_n);
+  hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, GL>), dim3(tiles_m * tiles_n), dim3(256), lds, st, a, tiles_n);
   if (prof) {
     static const std::string name = std::string("conv_gemm_x6<") + std::to_string(BM) + "x" + std::to_string(BN) +
                                     (PRO == PRO_SNAKE ? ",snake" : PRO == PRO_LRELU ? ",lrelu" : "") +
@@ -306,6 +335,11 @@ int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
 template <int BM, int BN, int WM, int WN, int PRO, int EPI>
 int x6_launch2(const ConvGemmArgs& a, hipStream_t st) {
   const int win = BM + (a.ntaps - 1) * a.tap_dil;
+  if constexpr (BM >= 128 && BN == 128 && PRO == PRO_NONE && EPI != 4) {
+    // Linear layers on the 128-row tiles: weight planes by LDS-DMA (two buffers: 73.7 / 79.9 KB, still two workgroups per CU)
+    static const bool no_glds = getenv("JV_NO_GLDS") != nullptr;
+    if (a.ntaps == 1 && !no_glds) return x6_launch3<BM, BN, WM, WN, PRO, EPI, (BM > 128 ? 2 : 1), true>(a, st);
+  }
   if constexpr (BM > 128) {
     if (win > 256) return fail(JV_ERR_ARG, "conv_gemm_x6: window too tall for this tile variant");
     return x6_launch3<BM, BN, WM, WN, PRO, EPI, 2>(a, st);
