@@ -53,7 +53,7 @@ __device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& h, u32x4& m
 // MFMA phase ahead, instead of through registers and ds_write_b128 between the two barriers of a step; both LDS images
 // are then unpadded 64-byte rows whose 16-byte slots are XOR-swizzled with (row >> 2) & 3 (for W on the SOURCE address:
 // the DMA writes lane-linear), which keeps every ds_read_b128 lane group on 64 distinct banks.  1-tap (Linear) shapes only.
-template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, bool GL = false>
+template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int GL = 0>
 __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EPI != 4) ? 5 : 2) void conv_gemm_x6_kernel(const ConvGemmArgs p, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = WM / 32, NT = WN / 32;
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
   };
 
   // GL: 3 * BN / 16 one-KiB pieces (16 weight rows x 64 B of one plane) per step, dealt round-robin to the four waves
-  auto dma_W = [&](int c0, int buf) {
-    if constexpr (GL) {
+  auto dma_W = [&](int kb, int buf) {      // kb: first k column (tap * Cin + chunk * 32)
+    if constexpr (GL != 0) {
       constexpr int PIECES = 3 * BN / 16;
 #pragma unroll
       for (int i = 0; i < PIECES / 4; ++i) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
         const int row = g16 * 16 + (lane >> 2);
         const int kslot = (lane & 3) ^ ((row >> 2) & 3);
         const int n = min(n0 + row, p.n_rows_w - 1);      // rows past the weight matrix feed columns that are never stored
-        const unsigned short* src = p.W3 + (long)plane * p.w3_plane + (long)n * p.ldw + c0 + 8 * kslot;
+        const unsigned short* src = p.W3 + (long)plane * p.w3_plane + (long)n * p.ldw + kb + 8 * kslot;
         unsigned char* dst = ldsW + ((buf * 3 + plane) * BN + g16 * 16) * 64;      // wave-uniform; the DMA adds lane * 16
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -206,36 +206,39 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
   const int nchunks = p.Cin >> 5;
   const int nsteps = nchunks * ntaps;
   load_A(0);
-  if constexpr (GL) dma_W(0, 0);
-  else load_W(0, 0);
+  if constexpr (GL == 2) dma_W(0, 0);
+  else if constexpr (GL == 0) load_W(0, 0);
   if (JV_STAMP(p)) t_loop = __builtin_amdgcn_s_memtime();
   int c = 0, j = 0;
   for (int s = 0; s < nsteps; ++s) {
     if (!JV_ABLATE(p, 4)) __syncthreads();
+    if constexpr (GL == 1) dma_W(j * p.Cin + c * 32, 0);      // lands while this wave splits and stores its A rows
     if (!JV_ABLATE(p, 2)) {
       if (j == 0) store_A(c * 32);
-      if constexpr (!GL) store_W();
+      if constexpr (GL == 0) store_W();
     }
-    if (!JV_ABLATE(p, 4)) __syncthreads();      // GL: its vmcnt(0) also retires this step's weight DMA, issued a phase ago
+    if (!JV_ABLATE(p, 4)) __syncthreads();      // GL: the vmcnt(0) in front of a barrier also retires this step's weight DMA
     int j2 = j + 1, c2 = c;
     if (j2 == ntaps) { j2 = 0; c2 = c + 1; }
     if (s + 1 < nsteps && !JV_ABLATE(p, 1)) {
       if (j2 == 0) load_A(c2 * 32);
-      if constexpr (GL) dma_W(c2 * 32, (s + 1) & 1);      // that buffer was last read in step s - 1, before the barriers above
-      else load_W(j2, c2 * 32);
+      if constexpr (GL == 2) dma_W(j2 * p.Cin + c2 * 32, (s + 1) & 1);   // that buffer was last read in step s - 1, before the barriers above
+      else if constexpr (GL == 0) load_W(j2, c2 * 32);
     }
     const unsigned char* la = ldsA + (wm * WM + r32 + j * dil) * ROWB + (GL ? 0 : 16 * half);
-    const unsigned char* lw = ldsW + (GL ? (s & 1) * 3 * BN * 64 : 0) + (wn * WN + r32) * ROWB + (GL ? 0 : 16 * half);
-    const int swz = (r32 >> 2) & 3;             // GL: WM, WN and the 32-row fragment steps are multiples of 16 rows
+    const unsigned char* lw = ldsW + (GL == 2 ? (s & 1) * 3 * BN * 64 : 0) + (wn * WN + r32) * ROWB + (GL ? 0 : 16 * half);
+    // GL: WM, WN and the 32-row fragment steps are multiples of 16 rows, so only r32 (and the tap's row offset) enter the key
+    const int swz = (r32 >> 2) & 3, swza = ((r32 + j * dil) >> 2) & 3;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {            // two k-steps of 16 per 32-channel chunk
       bf16x8 a[MT][3], b[NT][3];
       const int koff = GL ? (((2 * ks + half) ^ swz) << 4) : 32 * ks;
+      const int koffa = GL ? (((2 * ks + half) ^ swza) << 4) : 32 * ks;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-          a[mt][pl] = *reinterpret_cast<const bf16x8*>(la + (pl * win + mt * 32) * ROWB + koff);
+          a[mt][pl] = *reinterpret_cast<const bf16x8*>(la + (pl * win + mt * 32) * ROWB + koffa);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -266,12 +269,12 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
 namespace {
 
 template <int BM, int BN>
-size_t x6_lds_bytes(const ConvGemmArgs& a, bool gl = false) {
+size_t x6_lds_bytes(const ConvGemmArgs& a, int gl = 0) {
   const int win = BM + (a.ntaps - 1) * a.tap_dil;
-  return gl ? (size_t)3 * (win + 2 * BN) * 64 : (size_t)3 * (win + BN) * X6_ROWB;
+  return gl ? (size_t)3 * (win + gl * BN) * 64 : (size_t)3 * (win + BN) * X6_ROWB;
 }
 
-template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, bool GL = false>
+template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int GL = 0>
 int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
   static bool raised = false;
   if (!raised) {
@@ -338,7 +341,11 @@ int x6_launch2(const ConvGemmArgs& a, hipStream_t st) {
   if constexpr (BM >= 128 && BN == 128 && PRO == PRO_NONE && EPI != 4) {
     // Linear layers on the 128-row tiles: weight planes by LDS-DMA (two buffers: 73.7 / 79.9 KB, still two workgroups per CU)
     static const bool no_glds = getenv("JV_NO_GLDS") != nullptr;
-    if (a.ntaps == 1 && !no_glds) return x6_launch3<BM, BN, WM, WN, PRO, EPI, (BM > 128 ? 2 : 1), true>(a, st);
+    if (a.ntaps == 1 && !no_glds) return x6_launch3<BM, BN, WM, WN, PRO, EPI, (BM > 128 ? 2 : 1), 2>(a, st);
+  }
+  if constexpr (BM == 64 && BN == 64 && PRO == PRO_NONE && EPI != 4) {
+    static const bool no_glds1 = getenv("JV_NO_GLDS1") != nullptr;
+    if (win <= 128 && !no_glds1) return x6_launch3<BM, BN, WM, WN, PRO, EPI, 1, 1>(a, st);
   }
   if constexpr (BM > 128) {
     if (win > 256) return fail(JV_ERR_ARG, "conv_gemm_x6: window too tall for this tile variant");
