@@ -8,10 +8,13 @@
 // v_mfma_f32_32x32x16_bf16 delivers a 32x32x16 block in 32 cycles against 8 x 64 cycles for v_mfma_f32_32x32x2_f32:
 // 6 x 32 = 192 vs 512 cycles per 16 k, i.e. 2.67x less matrix-pipe time for the same fp32-accurate contraction.
 //
-// Weights are split once at load time (registry.hip, three bf16 planes in HBM, 6 B per weight); activations are split
-// while the A window is staged into LDS (after the Snake / LeakyReLU / mask prologue), once per workgroup and K-chunk.
-// LDS rows are 80 B (32 bf16 + 16 B pad) so the ds_read_b128 operand fetches (8 consecutive k of one row per lane) are
-// bank-conflict free.  Everything outside the main loop (tile order, masks, epilogue) is shared with conv_gemm.hip.
+// Weights are split once at load time (registry.hip, three bf16 planes in HBM, 6 B per weight) and travel global -> LDS by
+// LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write); activations are split while the A window is staged
+// into LDS through registers (after the Snake / LeakyReLU / mask prologue), once per workgroup and K-chunk.
+// Both LDS images are unpadded 64-byte rows (32 bf16) whose 16-byte slots are XOR-swizzled with (row >> 2) & 3 -- for W on
+// the SOURCE address, since the DMA writes lane-linear -- which keeps every ds_read_b128 lane group (8 consecutive k of
+// one row per lane) on 64 distinct banks.  Everything outside the main loop (tile order, masks, epilogue) is shared with
+// conv_gemm.hip.
 #include <math.h>
 #include <stdlib.h>
 
@@ -30,7 +33,7 @@ namespace jv {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int X6_ROWB = 80;   // bytes per LDS row: 32 bf16 + pad
+constexpr int ROWB = 64;      // bytes per LDS row: 32 bf16, 16-byte slots swizzled
 
 __device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
   bf16x8 hh, mm, ll;
@@ -48,18 +51,16 @@ __device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& h, u32x4& m
 
 // The 64x64 plain variants are held to 96 registers so five workgroups fit a CU: the N = 256 GEMMs of the estimator
 // make 1220 such tiles, which then all run in one resident wave (1280 slots) instead of 1024 + a 20 % tail.
-// NA2: window rows staged per thread (rows tid>>1 + 128 i): 1 when the A window fits 128 rows, else 2
-// GL: the weight planes go global -> LDS by LDS-DMA (global_load_lds_dwordx4) into two alternating buffers, issued a whole
-// MFMA phase ahead, instead of through registers and ds_write_b128 between the two barriers of a step; both LDS images
-// are then unpadded 64-byte rows whose 16-byte slots are XOR-swizzled with (row >> 2) & 3 (for W on the SOURCE address:
-// the DMA writes lane-linear), which keeps every ds_read_b128 lane group on 64 distinct banks.  1-tap (Linear) shapes only.
-template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int GL = 0>
+// NA2: window rows staged per thread (rows tid>>1 + 128 i): 1 when the A window fits 128 rows, else 2.
+// NWB: weight buffers in LDS.  2: the DMA for step s + 1 is issued behind step s's barriers and lands during its MFMAs;
+// 1: the DMA is issued between the two barriers of its own step and lands while the wave splits and stores its A rows.
+template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int NWB>
 __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EPI != 4) ? 5 : 2) void conv_gemm_x6_kernel(const ConvGemmArgs p, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-  constexpr int NW = (3 * BN * 4) / 256;       // 16-byte weight pieces per thread per step
+  static_assert(NWB == 1 || NWB == 2, "one or two weight buffers");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -81,9 +82,8 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
 
   const int ntaps = p.ntaps, dil = p.tap_dil;
   const int win = BM + (ntaps - 1) * dil;
-  constexpr int ROWB = GL ? 64 : X6_ROWB;
-  unsigned char* const ldsA = reinterpret_cast<unsigned char*>(smem);            // [3][win][ROWB]
-  unsigned char* const ldsW = ldsA + 3 * win * ROWB;                             // [3][BN][80 B], or GL: [2][3][BN][64 B]
+  unsigned char* const ldsA = reinterpret_cast<unsigned char*>(smem);            // [3][win][64 B]
+  unsigned char* const ldsW = ldsA + 3 * win * ROWB;                             // [NWB][3][BN][64 B]
 
   unsigned avalid = 0;
 #pragma unroll
@@ -96,9 +96,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
   }
 
   f32x4 pa[NA2][4];
-  u32x4 pw[NW];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const u32x4 zerou = {0u, 0u, 0u, 0u};
 
   auto load_A = [&](int c0) {
 #pragma unroll
@@ -107,18 +105,6 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
       const float* src = A + ar * p.lda + c0 + 16 * khalf;
 #pragma unroll
       for (int v = 0; v < 4; ++v) pa[i][v] = ((avalid >> i) & 1u) ? *reinterpret_cast<const f32x4*>(src + 4 * v) : zero4;
-    }
-  };
-  auto load_W = [&](int j, int c0) {
-    const int kb = j * p.Cin + c0;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int idx = tid + 256 * i;
-      const int plane = idx / (BN * 4), rem = idx % (BN * 4);
-      const int n = n0 + (rem >> 2), c8 = rem & 3;
-      pw[i] = (n < p.n_rows_w)
-                  ? *reinterpret_cast<const u32x4*>(p.W3 + (long)plane * p.w3_plane + (long)n * p.ldw + kb + 8 * c8)
-                  : zerou;
     }
   };
   auto store_A = [&](int c0) {
@@ -158,8 +144,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
           }
           u32x4 h, m, l;
           split3x8(x, h, m, l);
-          unsigned char* dst = GL ? ldsA + r * 64 + (((2 * khalf + g) ^ ((r >> 2) & 3)) << 4)
-                                  : ldsA + r * X6_ROWB + (16 * khalf + 8 * g) * 2;
+          unsigned char* dst = ldsA + r * ROWB + (((2 * khalf + g) ^ ((r >> 2) & 3)) << 4);
           *reinterpret_cast<u32x4*>(dst) = h;
           *reinterpret_cast<u32x4*>(dst + win * ROWB) = m;
           *reinterpret_cast<u32x4*>(dst + 2 * win * ROWB) = l;
@@ -167,31 +152,21 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
       }
     }
   };
-  auto store_W = [&]() {
+  // 3 * BN / 16 one-KiB pieces (16 weight rows x 64 B of one plane) per step, dealt round-robin to the four waves.
+  // Lane L of a piece lands in LDS row L >> 2, slot L & 3, and therefore fetches k-slot (L & 3) ^ swizzle(row).
+  auto dma_W = [&](int kb, int buf) {      // kb: first k column of the step (tap * Cin + chunk * 32)
+    constexpr int PIECES = 3 * BN / 16;
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int idx = tid + 256 * i;
-      const int plane = idx / (BN * 4), rem = idx % (BN * 4);
-      *reinterpret_cast<u32x4*>(ldsW + (plane * BN + (rem >> 2)) * X6_ROWB + (rem & 3) * 16) = pw[i];
-    }
-  };
-
-  // GL: 3 * BN / 16 one-KiB pieces (16 weight rows x 64 B of one plane) per step, dealt round-robin to the four waves
-  auto dma_W = [&](int kb, int buf) {      // kb: first k column (tap * Cin + chunk * 32)
-    if constexpr (GL != 0) {
-      constexpr int PIECES = 3 * BN / 16;
-#pragma unroll
-      for (int i = 0; i < PIECES / 4; ++i) {
-        const int pc = wave + 4 * i;
-        const int plane = pc / (BN / 16), g16 = pc % (BN / 16);
-        const int row = g16 * 16 + (lane >> 2);
-        const int kslot = (lane & 3) ^ ((row >> 2) & 3);
-        const int n = min(n0 + row, p.n_rows_w - 1);      // rows past the weight matrix feed columns that are never stored
-        const unsigned short* src = p.W3 + (long)plane * p.w3_plane + (long)n * p.ldw + kb + 8 * kslot;
-        unsigned char* dst = ldsW + ((buf * 3 + plane) * BN + g16 * 16) * 64;      // wave-uniform; the DMA adds lane * 16
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-      }
+    for (int i = 0; i < PIECES / 4; ++i) {
+      const int pc = wave + 4 * i;
+      const int plane = pc / (BN / 16), g16 = pc % (BN / 16);
+      const int row = g16 * 16 + (lane >> 2);
+      const int kslot = (lane & 3) ^ ((row >> 2) & 3);
+      const int n = min(n0 + row, p.n_rows_w - 1);      // rows past the weight matrix feed columns that are never stored
+      const unsigned short* src = p.W3 + (long)plane * p.w3_plane + (long)n * p.ldw + kb + 8 * kslot;
+      unsigned char* dst = ldsW + ((buf * 3 + plane) * BN + g16 * 16) * ROWB;      // wave-uniform; the DMA adds lane * 16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
   };
 
@@ -206,34 +181,33 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
   const int nchunks = p.Cin >> 5;
   const int nsteps = nchunks * ntaps;
   load_A(0);
-  if constexpr (GL == 2) dma_W(0, 0);
-  else if constexpr (GL == 0) load_W(0, 0);
+  if constexpr (NWB == 2) dma_W(0, 0);
   if (JV_STAMP(p)) t_loop = __builtin_amdgcn_s_memtime();
   int c = 0, j = 0;
   for (int s = 0; s < nsteps; ++s) {
-    if (!JV_ABLATE(p, 4)) __syncthreads();
-    if constexpr (GL == 1) dma_W(j * p.Cin + c * 32, 0);      // lands while this wave splits and stores its A rows
+    if (!JV_ABLATE(p, 4)) __syncthreads();      // every wave is done reading the previous step's LDS images
+    if constexpr (NWB == 1) dma_W(j * p.Cin + c * 32, 0);
     if (!JV_ABLATE(p, 2)) {
       if (j == 0) store_A(c * 32);
-      if constexpr (GL == 0) store_W();
     }
-    if (!JV_ABLATE(p, 4)) __syncthreads();      // GL: the vmcnt(0) in front of a barrier also retires this step's weight DMA
+    // __syncthreads() drains vmcnt before its barrier, which retires this step's weight DMA in every wave: LDS-DMA data
+    // may be read only after the issuing waves' vmcnt wait AND a barrier the reader has passed
+    if (!JV_ABLATE(p, 4)) __syncthreads();
     int j2 = j + 1, c2 = c;
     if (j2 == ntaps) { j2 = 0; c2 = c + 1; }
     if (s + 1 < nsteps && !JV_ABLATE(p, 1)) {
       if (j2 == 0) load_A(c2 * 32);
-      if constexpr (GL == 2) dma_W(j2 * p.Cin + c2 * 32, (s + 1) & 1);   // that buffer was last read in step s - 1, before the barriers above
-      else if constexpr (GL == 0) load_W(j2, c2 * 32);
+      // buffer (s + 1) & 1 was last read in step s - 1, which every wave finished before the barriers above
+      if constexpr (NWB == 2) dma_W(j2 * p.Cin + c2 * 32, (s + 1) & 1);
     }
-    const unsigned char* la = ldsA + (wm * WM + r32 + j * dil) * ROWB + (GL ? 0 : 16 * half);
-    const unsigned char* lw = ldsW + (GL == 2 ? (s & 1) * 3 * BN * 64 : 0) + (wn * WN + r32) * ROWB + (GL ? 0 : 16 * half);
-    // GL: WM, WN and the 32-row fragment steps are multiples of 16 rows, so only r32 (and the tap's row offset) enter the key
-    const int swz = (r32 >> 2) & 3, swza = ((r32 + j * dil) >> 2) & 3;
+    const unsigned char* la = ldsA + (wm * WM + r32 + j * dil) * ROWB;
+    const unsigned char* lw = ldsW + (NWB == 2 ? (s & 1) * 3 * BN * ROWB : 0) + (wn * WN + r32) * ROWB;
+    // WM, WN and the 32-row fragment steps are multiples of 16 rows, so only r32 (and the tap's row offset) enter the keys
+    const int swzw = (r32 >> 2) & 3, swza = ((r32 + j * dil) >> 2) & 3;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {            // two k-steps of 16 per 32-channel chunk
       bf16x8 a[MT][3], b[NT][3];
-      const int koff = GL ? (((2 * ks + half) ^ swz) << 4) : 32 * ks;
-      const int koffa = GL ? (((2 * ks + half) ^ swza) << 4) : 32 * ks;
+      const int koffa = ((2 * ks + half) ^ swza) << 4, koffw = ((2 * ks + half) ^ swzw) << 4;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -243,7 +217,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-          b[nt][pl] = *reinterpret_cast<const bf16x8*>(lw + (pl * BN + nt * 32) * ROWB + koff);
+          b[nt][pl] = *reinterpret_cast<const bf16x8*>(lw + (pl * BN + nt * 32) * ROWB + koffw);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -269,20 +243,20 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
 namespace {
 
 template <int BM, int BN>
-size_t x6_lds_bytes(const ConvGemmArgs& a, int gl = 0) {
+size_t x6_lds_bytes(const ConvGemmArgs& a, int nwb = 1) {
   const int win = BM + (a.ntaps - 1) * a.tap_dil;
-  return gl ? (size_t)3 * (win + gl * BN) * 64 : (size_t)3 * (win + BN) * X6_ROWB;
+  return (size_t)3 * (win + nwb * BN) * ROWB;
 }
 
-template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int GL = 0>
+template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int NWB>
 int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
   static bool raised = false;
   if (!raised) {
-    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, GL>),
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, NWB>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     raised = true;
   }
-  size_t lds = x6_lds_bytes<BM, BN>(a, GL);
+  size_t lds = x6_lds_bytes<BM, BN>(a, NWB);
   const size_t need = (size_t)4 * 32 * (WN + 4) * sizeof(float);
   if (lds < need) lds = need;
   const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
@@ -298,7 +272,7 @@ int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, st);
-    hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, GL>), dim3(nwg), dim3(256), lds, st, b, tiles_n);
+    hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, NWB>), dim3(nwg), dim3(256), lds, st, b, tiles_n);
     (void)hipEventRecord(e1, st);
     (void)hipStreamSynchronize(st);
     float ms = 0.f;
@@ -321,7 +295,7 @@ int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
     }
     return JV_OK;
   }
-  hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, GL>), dim3(tiles_m * tiles_n), dim3(256), lds, st, a, tiles_n);
+  hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, NWB>), dim3(tiles_m * tiles_n), dim3(256), lds, st, a, tiles_n);
   if (prof) {
     static const std::string name = std::string("conv_gemm_x6<") + std::to_string(BM) + "x" + std::to_string(BN) +
                                     (PRO == PRO_SNAKE ? ",snake" : PRO == PRO_LRELU ? ",lrelu" : "") +
@@ -335,27 +309,19 @@ int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
   return JV_OK;
 }
 
+// Weight planes always travel by LDS-DMA: two W buffers when both fit beside the A window in half a CU's LDS (the DMA of
+// step s + 1 then runs behind step s's MFMAs), otherwise one.  The 64-row tiles always take one: a second buffer would cost
+// the 64x64 tile its fifth workgroup per CU.
 template <int BM, int BN, int WM, int WN, int PRO, int EPI>
 int x6_launch2(const ConvGemmArgs& a, hipStream_t st) {
   const int win = BM + (a.ntaps - 1) * a.tap_dil;
-  if constexpr (BM >= 128 && BN == 128 && PRO == PRO_NONE && EPI != 4) {
-    // Linear layers on the 128-row tiles: weight planes by LDS-DMA (two buffers: 73.7 / 79.9 KB, still two workgroups per CU)
-    static const bool no_glds = getenv("JV_NO_GLDS") != nullptr;
-    if (a.ntaps == 1 && !no_glds) return x6_launch3<BM, BN, WM, WN, PRO, EPI, (BM > 128 ? 2 : 1), 2>(a, st);
-  }
-  if constexpr (BM == 64 && BN == 64 && PRO == PRO_NONE && EPI != 4) {
-    static const bool no_glds1 = getenv("JV_NO_GLDS1") != nullptr;
-    if (win <= 128 && !no_glds1) return x6_launch3<BM, BN, WM, WN, PRO, EPI, 1, 1>(a, st);
-  }
-  if constexpr (BM > 128) {
-    if (win > 256) return fail(JV_ERR_ARG, "conv_gemm_x6: window too tall for this tile variant");
-    return x6_launch3<BM, BN, WM, WN, PRO, EPI, 2>(a, st);
+  if (win > (BM >= 128 ? 256 : 128)) return fail(JV_ERR_ARG, "conv_gemm_x6: window too tall for this tile variant");
+  if constexpr (BM >= 128) {
+    const bool two = x6_lds_bytes<BM, BN>(a, 2) <= 80 * 1024;
+    if (win > 128 || BM > 128) return two ? x6_launch3<BM, BN, WM, WN, PRO, EPI, 2, 2>(a, st) : x6_launch3<BM, BN, WM, WN, PRO, EPI, 2, 1>(a, st);
+    return two ? x6_launch3<BM, BN, WM, WN, PRO, EPI, 1, 2>(a, st) : x6_launch3<BM, BN, WM, WN, PRO, EPI, 1, 1>(a, st);
   } else {
-    if constexpr (BM == 128) {
-      if (win > 128) return x6_launch3<BM, BN, WM, WN, PRO, EPI, 2>(a, st);
-    }
-    if (win > 128) return fail(JV_ERR_ARG, "conv_gemm_x6: window too tall for this tile variant");
-    return x6_launch3<BM, BN, WM, WN, PRO, EPI, 1>(a, st);
+    return x6_launch3<BM, BN, WM, WN, PRO, EPI, 1, 1>(a, st);
   }
 }
 
