@@ -193,6 +193,18 @@ constexpr int AK_ROWB = 144, AV_ROWB = 80;
     (L) = (__bf16)(_r - (float)_m);           \
   } while (0)
 
+// combine a value with its partner lane's (lane ^ 32: the two lanes that hold one query's keys) in one VALU op:
+// v_permlane32_swap_b32 (gfx950) returns {own half | partner's low half, partner's high half | own}; ds_bpermute, what
+// __shfl_xor compiles to, is an LDS round trip
+__device__ __forceinline__ float half_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
@@ -356,7 +368,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
     float mt = s[0];
 #pragma unroll
     for (int e = 1; e < 16; ++e) mt = fmaxf(mt, s[e]);
-    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    mt = half_max(mt);
     const float m_new = fmaxf(m_run, mt);
     // v_exp_f32 directly: exp2f() wraps it in denormal-range scaling (6 more VALU ops per score); weights below 2^-126
     // flush to zero instead, far under the fp32 rounding of the row sum
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
       s[e] = __builtin_amdgcn_exp2f(s[e] - m_new);
       lt += s[e];
     }
-    lt += __shfl_xor(lt, 32);
+    lt = half_sum(lt);
     l_run = l_run * alpha + lt;
     m_run = m_new;
     if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {        // the running maximum moved for some query of this wave
