@@ -12,7 +12,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    m = re.search(r"conv_gemm_x6_kernel<(\d+), (\d+), \d+, \d+, (\d), (\d), (\d)>", name)
+    m = re.search(r"conv_gemm_x6_kernel<(\d+), (\d+), \d+, \d+, (\d), (\d), (\d)(?:, \d+)?>", name)
     if m:
         pro = {"0": "", "1": ",snake", "2": ",lrelu"}[m.group(3)]
         epi = {"0": "", "1": ",gelu", "2": ",res", "4": ",generic"}.get(m.group(4), "")
