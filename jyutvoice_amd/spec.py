@@ -238,12 +238,73 @@ def _hift_inventory() -> "OrderedDict[str, tuple]":
     return inv
 
 
+# ---- prompt (voice-cloning) branch: FlowEncoder of infer.py:35-83 = Embedding(6561, 512) ->
+# UpsampleConformerEncoder (jyutvoice/transformer/upsample_encoder.py:137-375, CosyVoice2 settings: 512-d, 8 heads,
+# FFN 2048, 6 + 4 pre-LN rel-pos blocks, no conv module, no macaron, static_chunk_size 25) -> Linear(512, 80)
+PROMPT_VOCAB = 6561
+PROMPT_DIM = 512
+PROMPT_HEADS = 8
+PROMPT_FFN = 2048
+PROMPT_BLOCKS = 6
+PROMPT_UP_BLOCKS = 4
+PROMPT_LOOKAHEAD = 3
+PROMPT_UP_STRIDE = 2
+PROMPT_STATIC_CHUNK = 25
+
+
+def _prompt_inventory() -> "OrderedDict[str, tuple]":
+    inv: "OrderedDict[str, tuple]" = OrderedDict()
+    D, F = PROMPT_DIM, PROMPT_FFN
+    inv["input_embedding.weight"] = (PROMPT_VOCAB, D)
+
+    def embed(pre):
+        inv[pre + "out.0.weight"] = (D, D)
+        inv[pre + "out.0.bias"] = (D,)
+        inv[pre + "out.1.weight"] = (D,)
+        inv[pre + "out.1.bias"] = (D,)
+
+    def block(pre):
+        inv[pre + "self_attn.pos_bias_u"] = (PROMPT_HEADS, D // PROMPT_HEADS)
+        inv[pre + "self_attn.pos_bias_v"] = (PROMPT_HEADS, D // PROMPT_HEADS)
+        for n in ("q", "k", "v", "out"):
+            inv[pre + f"self_attn.linear_{n}.weight"] = (D, D)
+            inv[pre + f"self_attn.linear_{n}.bias"] = (D,)
+        inv[pre + "self_attn.linear_pos.weight"] = (D, D)
+        inv[pre + "feed_forward.w_1.weight"] = (F, D)
+        inv[pre + "feed_forward.w_1.bias"] = (F,)
+        inv[pre + "feed_forward.w_2.weight"] = (D, F)
+        inv[pre + "feed_forward.w_2.bias"] = (D,)
+        for n in ("norm_ff", "norm_mha"):
+            inv[pre + n + ".weight"] = (D,)
+            inv[pre + n + ".bias"] = (D,)
+
+    embed("encoder.embed.")
+    inv["encoder.after_norm.weight"] = (D,)
+    inv["encoder.after_norm.bias"] = (D,)
+    inv["encoder.pre_lookahead_layer.conv1.weight"] = (D, D, PROMPT_LOOKAHEAD + 1)
+    inv["encoder.pre_lookahead_layer.conv1.bias"] = (D,)
+    inv["encoder.pre_lookahead_layer.conv2.weight"] = (D, D, 3)
+    inv["encoder.pre_lookahead_layer.conv2.bias"] = (D,)
+    for i in range(PROMPT_BLOCKS):
+        block(f"encoder.encoders.{i}.")
+    inv["encoder.up_layer.conv.weight"] = (D, D, 2 * PROMPT_UP_STRIDE + 1)
+    inv["encoder.up_layer.conv.bias"] = (D,)
+    embed("encoder.up_embed.")
+    for i in range(PROMPT_UP_BLOCKS):
+        block(f"encoder.up_encoders.{i}.")
+    inv["encoder_proj.weight"] = (N_FEATS, D)
+    inv["encoder_proj.bias"] = (N_FEATS,)
+    return inv
+
+
 TTS_INVENTORY = _tts_inventory()
 HIFT_INVENTORY = _hift_inventory()
+PROMPT_INVENTORY = _prompt_inventory()
 
 # known-answer structural checks (README.md:171,233 of the reference)
 assert len(TTS_INVENTORY) == 117 + 12 + 910 + 2, len(TTS_INVENTORY)
 assert len(HIFT_INVENTORY) == 328, len(HIFT_INVENTORY)
+assert len(PROMPT_INVENTORY) == 1 + 206 + 2, len(PROMPT_INVENTORY)   # the instantiated reference encoder has 206 tensors
 
 
 def numel(shape: tuple) -> int:

@@ -34,7 +34,8 @@ def _randn(key: str, shape) -> torch.Tensor:
     return torch.randn(tuple(shape), generator=_gen(key), dtype=torch.float32)
 
 
-_GAIN_SUFFIX = (".gamma", "block.2.weight", "norm1.weight", "norm3.weight")
+_GAIN_SUFFIX = (".gamma", "block.2.weight", "norm1.weight", "norm3.weight",
+                "norm_mha.weight", "norm_ff.weight", "after_norm.weight", "embed.out.1.weight")   # prompt encoder LayerNorms
 _WN_G = (".parametrizations.weight.original0", ".weight_g")
 _WN_V = (".parametrizations.weight.original1", ".weight_v")
 
@@ -99,6 +100,23 @@ def tts_state_dict(fixed_duration: Optional[float] = None) -> Dict[str, torch.Te
 
 def hift_state_dict() -> Dict[str, torch.Tensor]:
     return synth_state_dict(spec.HIFT_INVENTORY)
+
+
+def prompt_state_dict() -> Dict[str, torch.Tensor]:
+    """Synthetic FlowEncoder (prompt branch) state-dict: infer.py:35-83 key names."""
+    return synth_state_dict(spec.PROMPT_INVENTORY)
+
+
+def prompt_tokens(n: int, n_tokens: int, lengths=None, first_index: int = 0):
+    """`n` synthetic speech-token sequences (ids < 6561, what the speech tokenizer of infer.py:85-163 emits), padded with 0."""
+    tok = torch.zeros(n, n_tokens, dtype=torch.int64)
+    lens = torch.tensor(lengths if lengths is not None else [n_tokens] * n, dtype=torch.int64)
+    for b in range(n):
+        g = torch.Generator(device="cpu")
+        g.manual_seed(4321 + first_index + b)
+        L = int(lens[b])
+        tok[b, :L] = torch.randint(0, spec.PROMPT_VOCAB, (L,), generator=g)
+    return tok, lens
 
 
 def rand_noise() -> torch.Tensor:

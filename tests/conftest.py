@@ -37,3 +37,9 @@ def hift_sd():
 def noise():
     from jyutvoice_amd import synth
     return synth.rand_noise()
+
+
+@pytest.fixture(scope="session")
+def prompt_sd():
+    from jyutvoice_amd import synth
+    return synth.prompt_state_dict()

@@ -279,6 +279,35 @@ def main():
     report["G10 streaming out"] = maxdiff(out10, oflow.estimator(tts_sd, x10, mask10, mu10, t10, spks10, cond10, streaming=True))
     save("G10_streaming", x=x10, mask=mask10, mu=mu10, t=t10, spks=spks10, cond=cond10, out=out10)
 
+    # ---- G11: prompt branch -- FlowEncoder (infer.py:35-83) on the imported UpsampleConformerEncoder ------------
+    # infer.py itself cannot be imported (onnxruntime, whisper, BertModel at module scope); its FlowEncoder is four lines
+    # around the importable encoder (embedding * mask -> encoder(streaming=False) -> Linear), restated here.
+    from jyutvoice.transformer.upsample_encoder import UpsampleConformerEncoder
+    from jyutvoice.utils.mask import make_pad_mask
+    from oracle import prompt as oprompt
+    uce = UpsampleConformerEncoder(output_size=512, attention_heads=8, linear_units=2048, num_blocks=6, dropout_rate=0.1,
+                                   positional_dropout_rate=0.1, attention_dropout_rate=0.1, normalize_before=True,
+                                   input_layer="linear", pos_enc_layer_type="rel_pos_espnet",
+                                   selfattention_layer_type="rel_selfattn", input_size=512, use_cnn_module=False,
+                                   macaron_style=False, static_chunk_size=25).eval()
+    psd = synth.prompt_state_dict()
+    uce.load_state_dict({k[len("encoder."):]: v for k, v in psd.items() if k.startswith("encoder.")}, strict=True)
+    assert len(uce.state_dict()) == 206 and set(psd) == set(spec.PROMPT_INVENTORY)
+    emb = nn.Embedding(spec.PROMPT_VOCAB, 512)
+    emb.weight.data.copy_(psd["input_embedding.weight"])
+    g11 = {}
+    for tag, Tk in (("a", 23), ("b", 50)):
+        tok, lens = synth.prompt_tokens(1, Tk, first_index=Tk)
+        m = (~make_pad_mask(lens)).float().unsqueeze(-1)
+        hr, _ = uce(emb(torch.clamp(tok, min=0)) * m, lens, streaming=False)
+        hr = F.linear(hr, psd["encoder_proj.weight"], psd["encoder_proj.bias"])
+        taps = {}
+        ho, hl = oprompt.flow_encoder(psd, tok, lens, taps=taps)
+        report[f"G11 prompt_h Tk={Tk}"] = maxdiff(hr, ho)
+        assert int(hl[0]) == 2 * Tk and hr.shape == (1, 2 * Tk, 80)
+        g11["tok_" + tag], g11["h_" + tag] = tok, hr
+    save("G11_prompt", **g11)
+
     # ---- G6: padded batch equals per-utterance calls ---------------------------------------------
     o0 = est(xin[:1], mask[:1], mu[:1], t[:1], spks[:1], cond[:1])
     o1 = est(xin[1:, :, :20], mask[1:, :, :20], mu[1:, :, :20], t[1:], spks[1:], cond[1:, :, :20])

@@ -114,3 +114,27 @@ def test_streaming_estimator(tts_sd):
     g = load_golden("G10_streaming")
     out = oflow.estimator(tts_sd, g["x"], g["mask"], g["mu"], g["t"], g["spks"], g["cond"], streaming=True)
     assert md(out, g["out"]) <= 2e-5
+
+
+def test_prompt_encoder(prompt_sd):
+    """FlowEncoder (infer.py:35-83) restatement against the imported UpsampleConformerEncoder, two prompt lengths; the
+    padded batch is defined as the per-utterance loop (the reference's only usage is B = 1)"""
+    from oracle import prompt as oprompt
+    g = load_golden("G11_prompt")
+    for tag in "ab":
+        tok = g["tok_" + tag]
+        h, hl = oprompt.flow_encoder(prompt_sd, tok, torch.tensor([tok.shape[1]]))
+        assert int(hl[0]) == 2 * tok.shape[1]
+        assert md(h, g["h_" + tag]) <= 1e-5
+    tok = torch.zeros(2, 50, dtype=torch.int64)
+    tok[0], tok[1, :23] = g["tok_b"][0], g["tok_a"][0]
+    h, hl = oprompt.flow_encoder(prompt_sd, tok, torch.tensor([50, 23]))
+    assert hl.tolist() == [100, 46]
+    assert md(h[0:1], g["h_b"]) <= 1e-5 and md(h[1:2, :46], g["h_a"]) <= 1e-5 and float(h[1, 46:].abs().max()) == 0.0
+    # rel_shift known answer: out[i, j] = x[i, j - i + T - 1]
+    T = 7
+    x = torch.arange(T * (2 * T - 1), dtype=torch.float32).view(1, 1, T, 2 * T - 1)
+    y = oprompt.rel_shift(x)
+    for i in range(T):
+        for j in range(T):
+            assert float(y[0, 0, i, j]) == float(x[0, 0, i, j - i + T - 1])
