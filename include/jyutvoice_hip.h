@@ -31,6 +31,8 @@ extern "C" {
 
 #define JV_MODEL_TTS 0  /* JyutVoiceTTS state-dict: encoder.*, dp.*, decoder.estimator.*, spk_embed_affine_layer.* */
 #define JV_MODEL_HIFT 1 /* HiFTGenerator state-dict                                                                */
+#define JV_MODEL_PROMPT 2 /* FlowEncoder state-dict (infer.py:35-83: input_embedding.*, encoder.*, encoder_proj.*) plus the
+                             host-computed "pos_enc.div_term" [256] (jyutvoice/transformer/embedding.py:239-242)     */
 
 typedef struct jv_context jv_context;
 
@@ -87,6 +89,15 @@ int jv_flow_set_graph(jv_context* ctx, int on);
  * per-utterance loop of the batch-1-only reference. */
 int jv_cfm_solve(jv_context* ctx, const float* mu, const int32_t* lens, const float* spks, const float* cond, int B, int T,
                  int n_timesteps, float temperature, const float* t_span_host, float* mel, void* stream);
+
+/* ---- prompt (voice-cloning) branch ---------------------------------------------------------------------
+ * jv_prompt_encoder_fwd: FlowEncoder.forward of the reference's infer.py:35-83 -- Embedding(clamp(token, 0)) * mask ->
+ * UpsampleConformerEncoder(streaming=False) (jyutvoice/transformer/upsample_encoder.py:329-375) -> Linear(512, 80): the
+ * `prompt_h` that JyutVoiceTTS.synthesise prepends to mu (jyutvoice_tts.py:213-225).
+ * tokens: int64 [B,Tk] speech-token ids (< 6561), token_len: int64 [B]; prompt_h: [B, 2*Tk, 80] (batch, time, channel),
+ * zero beyond 2*token_len[b].  B > 1 is the per-utterance loop of the B = 1 reference usage.  2*Tk <= max_frames. */
+int jv_prompt_encoder_fwd(jv_context* ctx, const int64_t* tokens, const int64_t* token_len, int B, int Tk, float* prompt_h,
+                          void* stream);
 
 /* ---- text encoder + duration predictor + length regulation ---------------------------------------------
  * jv_encoder_fwd: spk_embed_affine_layer(normalize(spk)) + TextEncoder.forward + DurationPredictor.forward

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("JYUTVOICE_HIP_LIB") or os.path.join(HERE, "libjyutvoi
 
 JV_MODEL_TTS = 0
 JV_MODEL_HIFT = 1
+JV_MODEL_PROMPT = 2
 
 ACT = {"none": 0, "relu": 1, "gelu": 2, "mish": 3, "elu": 4, "silu": 5}
 PRO = {"none": 0, "snake": 1, "lrelu": 2}
@@ -49,6 +50,7 @@ SIGNATURES = {
     "jv_flow_set_graph": (_i, [_p, _i]),
     "jv_cfm_solve": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
     "jv_encoder_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
+    "jv_prompt_encoder_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "jv_length_regulate": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _p, _i, _p, _p, _p]),
     "jv_hift_f0": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "jv_hift_source": (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),

@@ -98,6 +98,7 @@ void jv_destroy(jv_context* ctx) {
   jv::flow_ws_destroy(c);
   jv::hift_ws_destroy(c);
   jv::enc_ws_destroy(c);
+  jv::prompt_ws_destroy(c);
   delete ctx;
 }
 
@@ -156,7 +157,8 @@ int jv_load_noise(jv_context* ctx, const float* data, int64_t numel, int on_devi
 
 int jv_finalize(jv_context* ctx, int model, void* stream) {
   CTX_GUARD(ctx);
-  if (model != JV_MODEL_TTS && model != JV_MODEL_HIFT) return jv::fail(JV_ERR_ARG, "jv_finalize: unknown model id");
+  if (model != JV_MODEL_TTS && model != JV_MODEL_HIFT && model != JV_MODEL_PROMPT)
+    return jv::fail(JV_ERR_ARG, "jv_finalize: unknown model id");
   if (ctx->c.ready[model]) return JV_OK;
   if (model == JV_MODEL_TTS) jv::flow_graphs_drop(ctx->c);
   return jv::finalize_model(ctx->c, model, static_cast<hipStream_t>(stream));

@@ -19,7 +19,9 @@ constexpr int EST_IN = 320, EST_CH = 256, EST_TIME = 1024, EST_HEADS = 8, EST_IN
 constexpr int NOISE_FRAMES = 15000;
 constexpr int HIFT_CH = 512, HIFT_F0_CH = 512, HIFT_NFFT = 16, HIFT_HOP = 4, HIFT_HARM = 9;
 
-enum Model : int { MODEL_TTS = 0, MODEL_HIFT = 1 };
+constexpr int PR_DIM = 512, PR_HEADS = 8, PR_FFN = 2048, PR_BLOCKS = 6, PR_UP_BLOCKS = 4, PR_VOCAB = 6561;
+
+enum Model : int { MODEL_TTS = 0, MODEL_HIFT = 1, MODEL_PROMPT = 2 };
 
 struct RawTensor {
   std::string name;
@@ -81,6 +83,18 @@ struct HiftW {
   ResBlockW src_rb[3], rb[9];
 };
 
+// prompt branch: FlowEncoder of infer.py:35-83 (Embedding -> UpsampleConformerEncoder -> Linear)
+struct ConfBlockW { LnW n_mha, n_ff; GemmW qkv, pos, out, w1, w2; const float *u = nullptr, *v = nullptr; };
+struct PromptW {
+  const float* emb = nullptr;          // [6561][512]
+  const float* div = nullptr;          // [256] positional frequencies (host-computed, embedding.py:239-242)
+  GemmW emb_lin, up_emb_lin;           // LinearNoSubsampling.out.0
+  LnW emb_ln, up_emb_ln;               // .out.1 with gain and offset pre-multiplied by sqrt(512) (the xscale of the pos-enc)
+  GemmW look1, look2, up_conv, proj;
+  LnW after;
+  ConfBlockW blk[PR_BLOCKS], up[PR_UP_BLOCKS];
+};
+
 struct Buf {             // a device allocation owned by the context
   float* p = nullptr;
   size_t floats = 0;
@@ -92,10 +106,11 @@ struct Context {
   std::vector<RawTensor> raw;
   std::unordered_map<std::string, int> index;
   Arena raw_arena, packed;
-  bool ready[2] = {false, false};
+  bool ready[3] = {false, false, false};
   EstimatorW est;
   EncoderW enc;
   HiftW hift;
+  PromptW prompt;
   float* noise = nullptr;        // [80][15000] fixed CFM noise (device), supplied by the host
   bool noise_loaded = false;
   bool step_graphs = false;      // replay the Euler step as a captured hipGraph (jv_flow_set_graph; never under the profiler)
@@ -105,6 +120,7 @@ struct Context {
   struct FlowWs* flow = nullptr;
   struct HiftWs* hws = nullptr;
   struct EncWs* ews = nullptr;
+  struct PromptWs* pws = nullptr;
   std::string last_error;
 };
 
@@ -122,6 +138,10 @@ int flow_estimator(Context& c, const float* x, const int* lens_dev, const float*
                    const float* cond, int B2, int T, float* out, hipStream_t st);
 int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spks, const float* cond, int B, int T,
               int n_timesteps, float temperature, const float* t_span_host, float* mel, hipStream_t st);
+
+// prompt.hip
+int prompt_encoder_fwd(Context& c, const long* tok, const long* len, int B, int Tk, float* h_out, hipStream_t st);
+void prompt_ws_destroy(Context& c);
 
 }  // namespace jv
 

@@ -168,6 +168,36 @@ void build_registry(Context& c) {
     h.add(q + "weight_v", {HIFT_F0_CH, n == 0 ? N_FEATS : HIFT_F0_CH, 3});
   }
   h.wb("f0_predictor.classifier.", {1, HIFT_F0_CH});
+
+  // ---- prompt encoder (infer.py:35-83; upsample_encoder.py:137-300) -----------------------------------
+  Reg q{c, MODEL_PROMPT};
+  q.add("input_embedding.weight", {PR_VOCAB, PR_DIM});
+  auto embed = [&](const std::string& s) {
+    q.wb(s + "out.0.", {PR_DIM, PR_DIM});
+    q.gb(s + "out.1.", PR_DIM, "weight", "bias");
+  };
+  auto block = [&](const std::string& s) {
+    q.add(s + "self_attn.pos_bias_u", {PR_HEADS, PR_DIM / PR_HEADS});
+    q.add(s + "self_attn.pos_bias_v", {PR_HEADS, PR_DIM / PR_HEADS});
+    for (const char* n : {"q", "k", "v", "out"}) q.wb(s + "self_attn.linear_" + n + ".", {PR_DIM, PR_DIM});
+    q.add(s + "self_attn.linear_pos.weight", {PR_DIM, PR_DIM});
+    q.wb(s + "feed_forward.w_1.", {PR_FFN, PR_DIM});
+    q.wb(s + "feed_forward.w_2.", {PR_DIM, PR_FFN});
+    q.gb(s + "norm_ff.", PR_DIM, "weight", "bias");
+    q.gb(s + "norm_mha.", PR_DIM, "weight", "bias");
+  };
+  const std::string pe = "encoder.";
+  embed(pe + "embed.");
+  q.gb(pe + "after_norm.", PR_DIM, "weight", "bias");
+  q.wb(pe + "pre_lookahead_layer.conv1.", {PR_DIM, PR_DIM, 4});
+  q.wb(pe + "pre_lookahead_layer.conv2.", {PR_DIM, PR_DIM, 3});
+  for (int i = 0; i < PR_BLOCKS; ++i) block(pe + "encoders." + S(i) + ".");
+  q.wb(pe + "up_layer.conv.", {PR_DIM, PR_DIM, 5});
+  embed(pe + "up_embed.");
+  for (int i = 0; i < PR_UP_BLOCKS; ++i) block(pe + "up_encoders." + S(i) + ".");
+  q.wb("encoder_proj.", {N_FEATS, PR_DIM});
+  // not a state-dict entry: the positional encoding's 256 frequencies, supplied by the host mirror
+  q.add("pos_enc.div_term", {PR_DIM / 2});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -361,10 +391,61 @@ struct Packer {
 
 }  // namespace
 
+int scale_copy(const float* x, float* y, float s, int n, hipStream_t st);   // promptops.hip
+
 int finalize_model(Context& c, int model, hipStream_t st) {
   for (const RawTensor& t : c.raw)
     if (t.model == model && !t.loaded) return fail(JV_ERR_STATE, "missing tensor: " + t.name);
   Packer pk{c, st};
+
+  if (model == MODEL_PROMPT) {
+    PromptW& w = c.prompt;
+    const std::string e = "encoder.";
+    w.emb = pk.ptr("input_embedding.weight");
+    w.div = pk.ptr("pos_enc.div_term");
+    // x * sqrt(512) after the LayerNorm (embedding.py:268) folded into its gain and offset
+    auto scaled_ln = [&](const std::string& s) {
+      LnW r;
+      float* g = pk.alloc(PR_DIM);
+      float* b = pk.alloc(PR_DIM);
+      const float* g0 = pk.ptr(s + "weight");
+      const float* b0 = pk.ptr(s + "bias");
+      if (g && b && g0 && b0) {
+        const float xs = sqrtf((float)PR_DIM);
+        if (scale_copy(g0, g, xs, PR_DIM, st) != JV_OK || scale_copy(b0, b, xs, PR_DIM, st) != JV_OK) pk.rc = JV_ERR_HIP;
+        r.g = g; r.b = b;
+      }
+      return r;
+    };
+    auto block = [&](const std::string& s, ConfBlockW& k) {
+      k.n_mha = pk.ln(s + "norm_mha.", "weight", "bias");
+      k.n_ff = pk.ln(s + "norm_ff.", "weight", "bias");
+      k.qkv = pk.concat({s + "self_attn.linear_q.weight", s + "self_attn.linear_k.weight", s + "self_attn.linear_v.weight"},
+                        {s + "self_attn.linear_q.bias", s + "self_attn.linear_k.bias", s + "self_attn.linear_v.bias"}, PR_DIM,
+                        PR_DIM);
+      k.pos = pk.linear(s + "self_attn.linear_pos.weight", "", PR_DIM, PR_DIM);
+      k.out = pk.linear(s + "self_attn.linear_out.weight", s + "self_attn.linear_out.bias", PR_DIM, PR_DIM);
+      k.w1 = pk.linear(s + "feed_forward.w_1.weight", s + "feed_forward.w_1.bias", PR_FFN, PR_DIM);
+      k.w2 = pk.linear(s + "feed_forward.w_2.weight", s + "feed_forward.w_2.bias", PR_DIM, PR_FFN);
+      k.u = pk.ptr(s + "self_attn.pos_bias_u");
+      k.v = pk.ptr(s + "self_attn.pos_bias_v");
+    };
+    w.emb_lin = pk.linear(e + "embed.out.0.weight", e + "embed.out.0.bias", PR_DIM, PR_DIM);
+    w.emb_ln = scaled_ln(e + "embed.out.1.");
+    w.up_emb_lin = pk.linear(e + "up_embed.out.0.weight", e + "up_embed.out.0.bias", PR_DIM, PR_DIM);
+    w.up_emb_ln = scaled_ln(e + "up_embed.out.1.");
+    w.look1 = pk.conv_named(e + "pre_lookahead_layer.conv1.", PR_DIM, PR_DIM, 4);
+    w.look2 = pk.conv_named(e + "pre_lookahead_layer.conv2.", PR_DIM, PR_DIM, 3);
+    w.up_conv = pk.conv_named(e + "up_layer.conv.", PR_DIM, PR_DIM, 5);
+    w.after = pk.ln(e + "after_norm.", "weight", "bias");
+    w.proj = pk.linear("encoder_proj.weight", "encoder_proj.bias", N_FEATS, PR_DIM);
+    for (int i = 0; i < PR_BLOCKS; ++i) block(e + "encoders." + S(i) + ".", w.blk[i]);
+    for (int i = 0; i < PR_UP_BLOCKS; ++i) block(e + "up_encoders." + S(i) + ".", w.up[i]);
+    if (pk.rc != JV_OK) return pk.rc;
+    JV_HIP(hipStreamSynchronize(st));
+    c.ready[MODEL_PROMPT] = true;
+    return JV_OK;
+  }
 
   if (model == MODEL_TTS) {
     // ---------------- estimator ----------------

@@ -11,7 +11,7 @@ from typing import Dict, Optional
 import torch
 
 from . import _lib, spec
-from ._lib import JV_MODEL_HIFT, JV_MODEL_TTS, JvError, check
+from ._lib import JV_MODEL_HIFT, JV_MODEL_PROMPT, JV_MODEL_TTS, JvError, check
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -43,7 +43,7 @@ class Engine:
         self.device = torch.device("cuda", idx)
         check(self.lib.jv_create(C.byref(h), idx, max_batch, max_frames, max_tokens))
         self._h = h
-        self._loaded = {JV_MODEL_TTS: False, JV_MODEL_HIFT: False}
+        self._loaded = {JV_MODEL_TTS: False, JV_MODEL_HIFT: False, JV_MODEL_PROMPT: False}
 
     def close(self):
         if getattr(self, "_h", None):
@@ -130,6 +130,16 @@ class Engine:
         check(self.lib.jv_cfm_solve(self._h, _ptr(mu), _ptr(lens_d), _ptr(spks), _ptr(cond), B, T, int(n_timesteps),
                                     float(temperature), ts, _ptr(mel), _stream(self.device)))
         return mel
+
+    # ---- prompt branch --------------------------------------------------------------------------------
+    def prompt_encoder(self, token, token_len):
+        """FlowEncoder.forward (infer.py:66-83): token [B,Tk] int64, token_len [B] -> prompt_h [B, 2*Tk, 80]"""
+        B, Tk = token.shape
+        tok = token.to(device=self.device, dtype=torch.int64).contiguous()
+        tl = token_len.to(device=self.device, dtype=torch.int64).contiguous()
+        h = torch.empty(B, 2 * Tk, spec.N_FEATS, device=self.device)
+        check(self.lib.jv_prompt_encoder_fwd(self._h, _ptr(tok), _ptr(tl), B, Tk, _ptr(h), _stream(self.device)))
+        return h
 
     # ---- encoder --------------------------------------------------------------------------------------
     def encoder(self, x, x_lengths, lang, tone, word_pos, syllable_pos, spk_embed):
