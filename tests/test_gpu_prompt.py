@@ -26,7 +26,7 @@ def test_prompt_encoder_golden(fenc):
         tok = g["tok_" + tag]
         h, hl = fenc(tok, torch.tensor([tok.shape[1]]))
         assert h.shape == (1, 2 * tok.shape[1], 80) and int(hl[0]) == 2 * tok.shape[1]
-        assert md(h, g["h_" + tag]) <= 2e-4, tag
+        assert md(h, g["h_" + tag]) <= 5e-5, tag            # measured 6e-6 on outputs of magnitude 4
 
 
 def test_prompt_ragged_batch_equals_singles(fenc, prompt_sd):
@@ -37,7 +37,7 @@ def test_prompt_ragged_batch_equals_singles(fenc, prompt_sd):
     h, hl = fenc(tok, lens)
     want, wl = oprompt.flow_encoder(prompt_sd, tok, lens)
     assert hl.cpu().tolist() == wl.tolist() == [122, 34, 80]
-    assert md(h, want) <= 2e-4
+    assert md(h, want) <= 5e-5
     for b, L in enumerate([61, 17, 40]):
         assert float(h[b, 2 * L:].abs().max()) == 0.0 if L < 61 else True
         solo, _ = fenc(tok[b:b + 1, :L], lens[b:b + 1])
@@ -51,7 +51,7 @@ def test_prompt_longer_sequence_and_regrow(fenc, prompt_sd):
     tok, lens = synth.prompt_tokens(1, 150, first_index=9)
     h, _ = fenc(tok, lens)
     want, _ = oprompt.flow_encoder(prompt_sd, tok, lens)
-    assert md(h, want) <= 3e-4
+    assert md(h, want) <= 1e-4
     tok1, lens1 = synth.prompt_tokens(1, 1, first_index=3)
     h1, _ = fenc(tok1, lens1)
     want1, _ = oprompt.flow_encoder(prompt_sd, tok1, lens1)
