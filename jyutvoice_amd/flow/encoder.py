@@ -66,3 +66,21 @@ class FlowEncoder:
         return h, token_len.to(self.device) * spec.PROMPT_UP_STRIDE
 
     __call__ = forward
+
+
+def extract_flow_weights(state_dict: Dict[str, torch.Tensor]):
+    """Split a CosyVoice2 `flow.pt` state-dict the way scripts/download_pretrain_weights.py:168-214 does:
+    -> (flow-encoder part: `encoder.*`, `input_embedding.*`, `encoder_proj.*`;  decoder part: `decoder.*`,
+    `spk_embed_affine_layer.*`).  The first loads into `FlowEncoder`, the second into `JyutVoiceTTS.load_pretrain`."""
+    enc = {k: v for k, v in state_dict.items() if k.startswith(("encoder.", "input_embedding.", "encoder_proj."))}
+    dec = {k: v for k, v in state_dict.items() if k.startswith(("decoder.", "spk_embed_affine_layer."))}
+    return enc, dec
+
+
+def load_flow_encoder(flow_encoder_path, device="cuda:0"):
+    """infer.py:209-230: `FlowEncoder` with the weights of `flow_encoder.pt`, or None when no path is given"""
+    if flow_encoder_path is None:
+        return None
+    enc = FlowEncoder(device=device)
+    enc.load_state_dict(torch.load(flow_encoder_path, map_location="cpu", weights_only=True))
+    return enc.eval()

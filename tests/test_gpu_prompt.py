@@ -99,3 +99,34 @@ def test_prompted_synthesis_uses_prompt_h(fenc, prompt_sd):
                            u["syllable_pos"], u["spk_embed"], prompt_feat, prompt_h=ph_o, n_timesteps=4)
     assert res["mel"].shape == want["mel"].shape
     assert md(res["mel"], want["mel"]) <= 1e-3
+
+
+def test_checkpoint_files_roundtrip(tmp_path, prompt_sd):
+    """the reference's file layout (infer.py:209-230, 341-345; jyutvoice_tts.py:73-107): flow.pt split into flow_encoder.pt
+    and the decoder part loaded by load_pretrain, then a Lightning-style {"state_dict": ...} checkpoint for the rest"""
+    import jyutvoice_amd
+    from jyutvoice_amd import synth
+    from jyutvoice_amd.flow.encoder import extract_flow_weights, load_flow_encoder
+    tts_sd = synth.tts_state_dict()
+    flow_pt = dict(prompt_sd)
+    flow_pt.update({k: v for k, v in tts_sd.items() if k.startswith(("decoder.", "spk_embed_affine_layer."))})
+    enc_part, dec_part = extract_flow_weights(flow_pt)
+    torch.save(enc_part, tmp_path / "flow_encoder.pt")
+    torch.save(dec_part, tmp_path / "pretrain.pt")
+    torch.save({"state_dict": {k: v for k, v in tts_sd.items() if k not in dec_part}, "epoch": 3}, tmp_path / "tts.ckpt")
+    assert load_flow_encoder(None) is None
+    fe = load_flow_encoder(str(tmp_path / "flow_encoder.pt"))
+    tok, lens = synth.prompt_tokens(1, 12)
+    h, _ = fe(tok, lens)
+    tts, _ = jyutvoice_amd.build_default("cuda:0")
+    with pytest.raises(FileNotFoundError):
+        tts.load_pretrain(str(tmp_path / "nope.pt"))
+    missing, unexpected = tts.load_pretrain(str(tmp_path / "pretrain.pt"))
+    assert len(missing) == 117 + 12 and not unexpected
+    u = synth.batch(1, 16)
+    with pytest.raises(RuntimeError):
+        tts.synthesise(u["x"], u["x_lengths"], u["lang"], u["tone"], u["word_pos"], u["syllable_pos"], u["spk_embed"], None)
+    tts.load_pretrain(str(tmp_path / "tts.ckpt"))
+    res = tts.synthesise(u["x"], u["x_lengths"], u["lang"], u["tone"], u["word_pos"], u["syllable_pos"], u["spk_embed"],
+                         torch.zeros(1, 24, 80), prompt_h=h, n_timesteps=2)
+    assert res["mel"].shape[0] == 1 and torch.isfinite(res["mel"]).all()

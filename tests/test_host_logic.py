@@ -81,3 +81,21 @@ def test_partial_checkpoints_accumulate():
         tts.synthesise(*([torch.zeros(1, 4, dtype=torch.int64)] * 6), torch.zeros(1, 192), None)
     with pytest.raises(RuntimeError, match="size mismatch for dp.proj.bias"):
         tts.load_state_dict({"dp.proj.bias": torch.zeros(3)}, strict=False)
+
+
+def test_flow_checkpoint_split(tmp_path):
+    """scripts/download_pretrain_weights.py:168-214: a CosyVoice2 flow.pt splits into the FlowEncoder part and the part
+    JyutVoiceTTS.load_pretrain takes; together with an encoder/dp checkpoint the 1041 TTS tensors are complete"""
+    import torch
+    from jyutvoice_amd import spec
+    from jyutvoice_amd.flow.encoder import extract_flow_weights
+    flow_pt = {k: torch.zeros(1) for k in spec.PROMPT_INVENTORY}
+    flow_pt.update({k: torch.zeros(1) for k in spec.TTS_INVENTORY if k.startswith(("decoder.", "spk_embed_affine_layer."))})
+    flow_pt["length_regulator.model.0.weight"] = torch.zeros(1)       # present in the real file, used by neither part
+    enc, dec = extract_flow_weights(flow_pt)
+    assert set(enc) == set(spec.PROMPT_INVENTORY)
+    assert len(dec) == 910 + 2 and all(k in spec.TTS_INVENTORY for k in dec)
+    rest = [k for k in spec.TTS_INVENTORY if k not in dec]
+    assert len(rest) == 117 + 12 and all(k.startswith(("encoder.", "dp.")) for k in rest)
+    torch.save(enc, tmp_path / "flow_encoder.pt")
+    assert set(torch.load(tmp_path / "flow_encoder.pt", weights_only=True)) == set(enc)
