@@ -7,13 +7,17 @@ Flag names and defaults follow the reference CLI (infer.py:272-329 of indiejosep
 load the two state-dicts, `tts.synthesise(...)`, `hift.inference(mel)`, write a 24 kHz wav.
 
 The reference's front-ends are NOT part of this build: text -> ids needs its G2P stack
-(pycantonese / pypinyin / g2p_en), and --ref_audio needs two external ONNX models plus the prompt encoder.  Instead
-this CLI takes the five id lists and the 192-d speaker embedding directly:
+(pycantonese / pypinyin / g2p_en), and --ref_audio needs two external ONNX models (speech tokenizer, speaker embedding) and a
+mel extractor.  Instead this CLI takes their outputs directly:
 
     --tokens tokens.json     {"x": [...], "lang": [...], "tone": [...], "word_pos": [...], "syllable_pos": [...]}
                              (equal-length int lists = the output contract of jyutvoice/text/__init__.py:20-35 after
-                             `intersperse`), and optionally "spk_embed": [192 floats]
+                             `intersperse`), optionally "spk_embed": [192 floats], and for voice cloning
+                             "prompt_token": [speech-token ids] + "prompt_feat": [[80 floats] per frame] -- what
+                             infer.py:386-392 extracts from --ref_audio; the prompt encoder (--flow_encoder) then runs on
+                             the GPU exactly as infer.py:390-392 runs it
     --synthetic N            no checkpoint / no tokens: N synthetic tokens, key-hashed weights (smoke / demo)
+    --synthetic-prompt K     with --synthetic: also a synthetic K-token voice prompt through the prompt encoder
 
 With --text and no --tokens it explains what is missing instead of guessing.
 """
@@ -48,7 +52,7 @@ def main(argv=None):
     p.add_argument("--output", required=True, help="Output audio file path")
     p.add_argument("--config", default="configs/base.yaml", help="accepted for compatibility; the base.yaml constants are built in")
     p.add_argument("--tts_checkpoint", default="pretrained_models/epoch=0-step=55872.ckpt", help="Path to TTS model checkpoint")
-    p.add_argument("--flow_encoder", default="pretrained_models/flow_encoder.pt", help="unused (prompt encoder is out of scope)")
+    p.add_argument("--flow_encoder", default="pretrained_models/flow_encoder.pt", help="Path to flow encoder weights (voice prompt)")
     p.add_argument("--speech_tokenizer", default="pretrained_models/speech_tokenizer_v2.onnx", help="unused (front-end)")
     p.add_argument("--campplus", default="pretrained_models/campplus.onnx", help="unused (front-end)")
     p.add_argument("--hift", default="pretrained_models/hift.pt", help="Path to HiFT vocoder weights")
@@ -56,6 +60,7 @@ def main(argv=None):
     p.add_argument("--length_scale", type=float, default=0.9, help="Length scale for speech duration control")
     p.add_argument("--tokens", default=None, help="JSON with the five id lists (and optionally spk_embed)")
     p.add_argument("--synthetic", type=int, default=0, help="use N synthetic tokens and synthetic weights")
+    p.add_argument("--synthetic-prompt", type=int, default=0, help="with --synthetic: K synthetic prompt tokens (voice-cloning path)")
     p.add_argument("--seed", type=int, default=0, help="seed of the vocoder's source-noise draws")
     args = p.parse_args(argv)
 
@@ -70,12 +75,20 @@ def main(argv=None):
     print(f"Using device: {device} ({torch.cuda.get_device_name(0)})")
     tts, hift = jyutvoice_amd.build_default(device)
 
+    prompt_feat = prompt_h = None
     if args.synthetic:
         tts.load_state_dict(synth.tts_state_dict())
         hift.load_state_dict(synth.hift_state_dict())
         u = synth.batch(1, args.synthetic)
         ids = {k: u[k] for k in ("x", "lang", "tone", "word_pos", "syllable_pos")}
         spk = u["spk_embed"]
+        if args.synthetic_prompt:
+            from jyutvoice_amd.flow.encoder import FlowEncoder
+            flow_encoder = FlowEncoder(device=device)
+            flow_encoder.load_state_dict(synth.prompt_state_dict())
+            ptok, plen = synth.prompt_tokens(1, args.synthetic_prompt)
+            prompt_h, _ = flow_encoder(ptok, plen)
+            prompt_feat = torch.randn(1, 2 * args.synthetic_prompt, 80, generator=torch.Generator().manual_seed(args.seed))
     else:
         if not args.tokens:
             raise SystemExit("--text/--ref_audio need the reference's G2P and ONNX front-ends, which are outside this build; "
@@ -91,6 +104,13 @@ def main(argv=None):
         if any(v.shape[1] != n for v in ids.values()):
             raise SystemExit("tokens: the five id lists must have equal length")
         spk = torch.tensor(tok["spk_embed"], dtype=torch.float32).view(1, 192) if "spk_embed" in tok else torch.randn(1, 192)
+        if "prompt_token" in tok and "prompt_feat" in tok:      # infer.py:386-392 with the ONNX/mel outputs supplied
+            from jyutvoice_amd.flow.encoder import load_flow_encoder
+            print(f"Loading flow encoder from {args.flow_encoder}...")
+            flow_encoder = load_flow_encoder(args.flow_encoder, device)
+            ptok = torch.tensor(tok["prompt_token"], dtype=torch.int64).view(1, -1)
+            prompt_h, _ = flow_encoder(ptok, torch.tensor([ptok.shape[1]], dtype=torch.int64))
+            prompt_feat = torch.tensor(tok["prompt_feat"], dtype=torch.float32).view(1, -1, 80)
     tts = tts.eval().to(device)
     hift = hift.eval().to(device)
     hift.manual_seed(args.seed)
@@ -99,7 +119,7 @@ def main(argv=None):
     print("Running TTS synthesis...")
     start = time.time()
     result = tts.synthesise(x=ids["x"], x_lengths=x_lengths, lang=ids["lang"], tone=ids["tone"], word_pos=ids["word_pos"],
-                            syllable_pos=ids["syllable_pos"], prompt_feat=None, prompt_h=None, spk_embed=spk,
+                            syllable_pos=ids["syllable_pos"], prompt_feat=prompt_feat, prompt_h=prompt_h, spk_embed=spk,
                             n_timesteps=args.n_timesteps, length_scale=args.length_scale)
     wav, _ = hift.inference(result["mel"])
     torch.cuda.synchronize()

@@ -130,3 +130,11 @@ def test_checkpoint_files_roundtrip(tmp_path, prompt_sd):
     res = tts.synthesise(u["x"], u["x_lengths"], u["lang"], u["tone"], u["word_pos"], u["syllable_pos"], u["spk_embed"],
                          torch.zeros(1, 24, 80), prompt_h=h, n_timesteps=2)
     assert res["mel"].shape[0] == 1 and torch.isfinite(res["mel"]).all()
+
+
+def test_cli_with_voice_prompt(tmp_path):
+    """infer.py --synthetic with a synthetic voice prompt: the call sequence of the reference CLI incl. infer.py:386-392"""
+    import infer
+    out = tmp_path / "p.wav"
+    infer.main(["--output", str(out), "--synthetic", "20", "--synthetic-prompt", "10", "--n_timesteps", "2"])
+    assert out.stat().st_size > 44 + 2 * 480 * 10
