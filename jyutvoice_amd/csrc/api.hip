@@ -210,7 +210,7 @@ int jv_op_conv_gemm(const float* A, int64_t a_rows, int M, int Cin, int ntaps, i
   if (ln_g) { a.ln = 1; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = ln_eps; }
   a.rowmask_in = rowmask; a.rowmask_out = rowmask;
   a.res1 = res; a.ldr1 = N;
-  if (getenv("JV_OP_X6")) {   // exercise the bf16x6 main loop: split W into three bf16 planes on the fly
+  if (jv::dyn_env("JV_OP_X6")) {   // exercise the bf16x6 main loop: split W into three bf16 planes on the fly
     static unsigned short* scratch = nullptr;
     static size_t cap = 0;
     const size_t n = (size_t)N * ntaps * Cin;

@@ -297,7 +297,7 @@ int launch2(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
 template <int BM, int BN, int WM, int WN, int NAMAX, int PRO>
 int launch1(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
   const bool lean = !(a.N & 3) && !(a.ldo & 3) && (!a.res1 || !(a.ldr1 & 3)) && !a.res2 && !a.rowvec && !a.rowmask_out &&
-                    !a.accumulate && a.out_scale == 1.f && !getenv("JV_GENERIC_EPI");
+                    !a.accumulate && a.out_scale == 1.f && !dyn_env("JV_GENERIC_EPI");
   if (lean && a.act == ACT_NONE)
     return a.res1 ? launch2<BM, BN, WM, WN, NAMAX, PRO, 2>(a, nbatch, st) : launch2<BM, BN, WM, WN, NAMAX, PRO, 0>(a, nbatch, st);
   if (lean && a.act == ACT_GELU && PRO == PRO_NONE && !a.res1) return launch2<BM, BN, WM, WN, NAMAX, PRO_NONE, 1>(a, nbatch, st);
@@ -367,7 +367,7 @@ int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
                             a.rowvec_ld, a.res1, a.ldr1, a.out_scale, st);
   }
   if (const char* ab = tuning_env("JV_ABLATE")) const_cast<ConvGemmArgs&>(a).ablate = atoi(ab);
-  if (a.W3 && nbatch == 1 && (a.ldw & 7) == 0 && !getenv("JV_NO_X6")) return conv_gemm_x6(a, st);
+  if (a.W3 && nbatch == 1 && (a.ldw & 7) == 0 && !dyn_env("JV_NO_X6")) return conv_gemm_x6(a, st);
   // Tile choice: the kernel is MFMA-bound, so cost ~ (#workgroup waves over 256 CUs) x tile area, with a mild penalty
   // for the smaller tiles' lower operand reuse; a variant must fit two workgroups' double-buffered LDS on a CU.
   const int span = (a.ntaps - 1) * a.tap_dil;
@@ -384,7 +384,7 @@ int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
     const double cost = (double)cdivl(tiles, 256) * cands[i].bm * cands[i].bn / cands[i].eff;
     if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
   }
-  if (const char* force = getenv("JV_TILE")) {   // tuning aid: force a tile variant (0, 1, 2)
+  if (const char* force = dyn_env("JV_TILE")) {   // tuning aid: force a tile variant (0, 1, 2)
     const int f = atoi(force);
     if (f >= 0 && f <= 2 && !((f == 0 && 128 + span > 192) || (f > 0 && 64 + span > 128))) best = f;
   }

@@ -372,15 +372,15 @@ int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st) {
   // narrow outputs over very many rows (the vocoder's 64-channel stage, M ~ 1e6): a 128 x 64 tile (each wave 64 x 32) reads
   // LDS 0.75 times per MFMA instead of once and stages each weight row for twice the rows
   if (best == 2 && a.N <= 64 && a.M >= 128 * 512 && cands[4].bm + span <= cands[4].max_win && cands[4].lds <= 80 * 1024 &&
-      !getenv("JV_NO_T128x64"))
+      !dyn_env("JV_NO_T128x64"))
     best = 4;
-  if (best == 0 && lean && cands[3].bm + span <= cands[3].max_win && !getenv("JV_NO_T160")) {
+  if (best == 0 && lean && cands[3].bm + span <= cands[3].max_win && !dyn_env("JV_NO_T160")) {
     // both run two workgroups per CU: rounds of 512 resident tiles x rows per tile
     const long r128 = cdivl((long)cdiv(a.M, 128) * cdiv(a.N, 128), 512) * 128;
     const long r160 = cdivl((long)cdiv(a.M, 160) * cdiv(a.N, 128), 512) * 160;
     if ((double)r160 / cands[3].eff < (double)r128) best = 3;
   }
-  if (const char* force = getenv("JV_TILE")) {
+  if (const char* force = dyn_env("JV_TILE")) {
     const int f = atoi(force);
     if (f >= 0 && f <= 4 && cands[f].bm + span <= cands[f].max_win && (f != 3 || lean)) best = f;
   }

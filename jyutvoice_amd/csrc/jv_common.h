@@ -50,6 +50,14 @@ int fail(int code, const std::string& msg);      // set_error + return code
     if (_rc != JV_OK) return _rc; \
   } while (0)
 
+// Test / tuning switches that may change between calls (JV_TILE, JV_OP_X6, JV_NO_X6, ...) are looked up per launch only
+// when JV_DYNAMIC_ENV was set before the library's first launch (tests/conftest.py, tools/gemm_bench.py); a product
+// process never walks the environment on its launch path.
+inline const char* dyn_env(const char* name) {
+  static const bool on = getenv("JV_DYNAMIC_ENV") != nullptr;
+  return on ? getenv(name) : nullptr;
+}
+
 #ifdef JV_TUNING
 inline const char* tuning_env(const char* name) { return getenv(name); }
 #else

@@ -1,4 +1,6 @@
 import os
+
+os.environ.setdefault("JV_DYNAMIC_ENV", "1")   # let tests flip JV_TILE / JV_OP_X6 / ... between calls (csrc/jv_common.h)
 import sys
 
 import numpy as np

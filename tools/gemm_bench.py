@@ -10,6 +10,8 @@ import math
 import os
 import sys
 
+os.environ.setdefault("JV_DYNAMIC_ENV", "1")
+
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
