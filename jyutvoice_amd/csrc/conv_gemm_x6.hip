@@ -321,6 +321,9 @@ int x6_launch2(const ConvGemmArgs& a, hipStream_t st) {
     if (win > 128 || BM > 128) return two ? x6_launch3<BM, BN, WM, WN, PRO, EPI, 2, 2>(a, st) : x6_launch3<BM, BN, WM, WN, PRO, EPI, 2, 1>(a, st);
     return two ? x6_launch3<BM, BN, WM, WN, PRO, EPI, 1, 2>(a, st) : x6_launch3<BM, BN, WM, WN, PRO, EPI, 1, 1>(a, st);
   } else {
+    // Few tiles (small batches): occupancy cannot hide the weight DMA's latency, LDS is plentiful -> two W buffers
+    const long tiles = (long)cdiv(a.M, BM) * cdiv(a.N, BN);
+    if (tiles <= 1024 && x6_lds_bytes<BM, BN>(a, 2) <= 64 * 1024) return x6_launch3<BM, BN, WM, WN, PRO, EPI, 1, 2>(a, st);
     return x6_launch3<BM, BN, WM, WN, PRO, EPI, 1, 1>(a, st);
   }
 }
