@@ -225,3 +225,23 @@ def test_x6_every_tile_variant(dev, x6, monkeypatch, tile):
     w3 = torch.randn(N, K, 3, generator=g) / math.sqrt(3 * K)
     out = op_conv_gemm(A.to(dev), pack_conv(w3).to(dev), b.to(dev), ntaps=3, tap_row0=-2, M=M)
     assert rel_err(out, conv_rows_ref(A, w3, b, -2, 1)[:M]) < 2e-6
+
+
+@pytest.mark.parametrize("tile,K", [("0", 1024), ("2", 1024), ("3", 256), ("4", 512)])
+def test_x6_weight_dma_race_screen(dev, x6, monkeypatch, tile, K):
+    """the weight planes reach LDS by LDS-DMA, ordered only by vmcnt + barrier (csrc/conv_gemm_x6.hip): a misplaced read
+    shows up as rare wrong tiles, so every variant is replayed on a long K loop and must reproduce bit for bit -- and
+    match fp64 -- while other work keeps the memory system busy"""
+    from jyutvoice_amd.engine import op_conv_gemm
+    monkeypatch.setenv("JV_TILE", tile)
+    g = torch.Generator().manual_seed(int(tile) * 7 + K)
+    M, N = 3000, 384
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    first = op_conv_gemm(A, W, b)
+    assert rel_err(first, A.double().cpu() @ W.double().cpu().T + b.double().cpu()) < 2e-6
+    noise = torch.empty(64 << 20, device=dev)
+    for i in range(40):
+        noise.normal_()                                   # streaming writes in flight beside the GEMM
+        assert torch.equal(op_conv_gemm(A, W, b), first), i
