@@ -99,6 +99,15 @@ int jv_cfm_solve(jv_context* ctx, const float* mu, const int32_t* lens, const fl
 int jv_prompt_encoder_fwd(jv_context* ctx, const int64_t* tokens, const int64_t* token_len, int B, int Tk, float* prompt_h,
                           void* stream);
 
+/* jv_load_mel_basis / jv_mel_spectrogram: the prompt-mel front-end, `extract_speech_feat` of infer.py:166-186 ->
+ * `mel_spectrogram` of jyutvoice/utils/audio.py:18-63 (24 kHz, n_fft = win = 1920 periodic Hann, hop 480, reflect pad 720,
+ * center=False, |.| with the 1e-9 floor, 80 mel bands, log(clamp(., 1e-5))).
+ * basis: the [80][961] fp32 mel filterbank (librosa.filters.mel(sr=24000, n_fft=1920, n_mels=80, fmin=0, fmax=8000) in the
+ * reference -- data to this library); wav: [B, n_samples] in [-1, 1], n_samples > 720; mel: [B, 80, T],
+ * T = 1 + (n_samples - 480) / 480. */
+int jv_load_mel_basis(jv_context* ctx, const float* basis, int64_t numel, int on_device, void* stream);
+int jv_mel_spectrogram(jv_context* ctx, const float* wav, int B, int n_samples, float* mel, void* stream);
+
 /* ---- text encoder + duration predictor + length regulation ---------------------------------------------
  * jv_encoder_fwd: spk_embed_affine_layer(normalize(spk)) + TextEncoder.forward + DurationPredictor.forward
  * (jyutvoice/models/jyutvoice_tts.py:175-182, text_encoder.py:406-451, duration_predictor.py:48-60).

@@ -13,9 +13,10 @@ mel extractor.  Instead this CLI takes their outputs directly:
     --tokens tokens.json     {"x": [...], "lang": [...], "tone": [...], "word_pos": [...], "syllable_pos": [...]}
                              (equal-length int lists = the output contract of jyutvoice/text/__init__.py:20-35 after
                              `intersperse`), optionally "spk_embed": [192 floats], and for voice cloning
-                             "prompt_token": [speech-token ids] + "prompt_feat": [[80 floats] per frame] -- what
-                             infer.py:386-392 extracts from --ref_audio; the prompt encoder (--flow_encoder) then runs on
-                             the GPU exactly as infer.py:390-392 runs it
+                             "prompt_token": [speech-token ids] + either "prompt_feat": [[80 floats] per frame] or
+                             "prompt_wav_24k": "ref_24k.wav" (16-bit mono; its mel is extracted on the GPU as
+                             infer.py:386 does) -- what infer.py:386-392 gets from --ref_audio; the prompt encoder
+                             (--flow_encoder) then runs on the GPU exactly as infer.py:390-392 runs it
     --synthetic N            no checkpoint / no tokens: N synthetic tokens, key-hashed weights (smoke / demo)
     --synthetic-prompt K     with --synthetic: also a synthetic K-token voice prompt through the prompt encoder
 
@@ -41,6 +42,26 @@ def write_wav(path: str, wav, sample_rate: int = 24000) -> None:
         f.write(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVEfmt " +
                 struct.pack("<IHHIIHH", 16, 1, 1, sample_rate, sample_rate * 2, 2, 16) + b"data" + struct.pack("<I", len(pcm)))
         f.write(pcm)
+
+
+def read_wav_24k(path: str):
+    """16-bit PCM mono 24 kHz wav -> [1, n] float in [-1, 1] (torchaudio.load + resampling of infer.py:368-382 are front-end)"""
+    import torch
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise SystemExit(f"{path}: not a RIFF/WAVE file")
+    pos, fmt, pcm = 12, None, None
+    while pos + 8 <= len(data):
+        tag, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        if tag == b"fmt ":
+            fmt = struct.unpack("<HHIIHH", data[pos + 8:pos + 24])
+        elif tag == b"data":
+            pcm = data[pos + 8:pos + 8 + size]
+        pos += 8 + size + (size & 1)
+    if fmt is None or pcm is None or fmt[0] != 1 or fmt[1] != 1 or fmt[2] != 24000 or fmt[5] != 16:
+        raise SystemExit(f"{path}: need 16-bit PCM, mono, 24 kHz (resample with the reference's front-end first)")
+    return (torch.frombuffer(bytearray(pcm), dtype=torch.int16).float() / 32768.0).unsqueeze(0)
 
 
 def main(argv=None):
@@ -104,13 +125,17 @@ def main(argv=None):
         if any(v.shape[1] != n for v in ids.values()):
             raise SystemExit("tokens: the five id lists must have equal length")
         spk = torch.tensor(tok["spk_embed"], dtype=torch.float32).view(1, 192) if "spk_embed" in tok else torch.randn(1, 192)
-        if "prompt_token" in tok and "prompt_feat" in tok:      # infer.py:386-392 with the ONNX/mel outputs supplied
+        if "prompt_token" in tok and ("prompt_feat" in tok or "prompt_wav_24k" in tok):   # infer.py:386-392
             from jyutvoice_amd.flow.encoder import load_flow_encoder
             print(f"Loading flow encoder from {args.flow_encoder}...")
             flow_encoder = load_flow_encoder(args.flow_encoder, device)
             ptok = torch.tensor(tok["prompt_token"], dtype=torch.int64).view(1, -1)
             prompt_h, _ = flow_encoder(ptok, torch.tensor([ptok.shape[1]], dtype=torch.int64))
-            prompt_feat = torch.tensor(tok["prompt_feat"], dtype=torch.float32).view(1, -1, 80)
+            if "prompt_wav_24k" in tok:
+                from jyutvoice_amd.utils.audio import extract_speech_feat
+                prompt_feat, _ = extract_speech_feat(read_wav_24k(tok["prompt_wav_24k"]), device)
+            else:
+                prompt_feat = torch.tensor(tok["prompt_feat"], dtype=torch.float32).view(1, -1, 80)
     tts = tts.eval().to(device)
     hift = hift.eval().to(device)
     hift.manual_seed(args.seed)

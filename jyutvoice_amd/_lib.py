@@ -50,6 +50,8 @@ SIGNATURES = {
     "jv_flow_set_graph": (_i, [_p, _i]),
     "jv_cfm_solve": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
     "jv_encoder_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
+    "jv_load_mel_basis": (_i, [_p, _p, _i64, _i, _p]),
+    "jv_mel_spectrogram": (_i, [_p, _p, _i, _i, _p, _p]),
     "jv_prompt_encoder_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "jv_length_regulate": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _p, _i, _p, _p, _p]),
     "jv_hift_f0": (_i, [_p, _p, _p, _i, _i, _p, _p]),

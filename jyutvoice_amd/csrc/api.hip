@@ -99,6 +99,7 @@ void jv_destroy(jv_context* ctx) {
   jv::hift_ws_destroy(c);
   jv::enc_ws_destroy(c);
   jv::prompt_ws_destroy(c);
+  jv::audio_ws_destroy(c);
   delete ctx;
 }
 

@@ -69,7 +69,7 @@ inline long cdivl(long a, long b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 
 // ---- implicit-GEMM convolution (conv_gemm.hip) -------------------------------------------------
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_MISH = 3, ACT_ELU = 4, ACT_SILU = 5 };
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_MISH = 3, ACT_ELU = 4, ACT_SILU = 5, ACT_LOGCLIP = 6 };
 enum Pro : int { PRO_NONE = 0, PRO_SNAKE = 1, PRO_LRELU = 2 };
 
 struct ConvGemmArgs {

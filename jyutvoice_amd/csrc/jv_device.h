@@ -20,6 +20,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     }
     case ACT_ELU: return v > 0.f ? v : expm1f(v);
     case ACT_SILU: return v / (1.f + expf(-v));
+    case ACT_LOGCLIP: return logf(fmaxf(v, 1e-5f));   // dynamic_range_compression of utils/audio.py:9-10
     default: return v;
   }
 }

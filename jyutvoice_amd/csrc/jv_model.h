@@ -121,6 +121,7 @@ struct Context {
   struct HiftWs* hws = nullptr;
   struct EncWs* ews = nullptr;
   struct PromptWs* pws = nullptr;
+  struct AudioWs* aws = nullptr;
   std::string last_error;
 };
 
@@ -142,6 +143,9 @@ int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spk
 // prompt.hip
 int prompt_encoder_fwd(Context& c, const long* tok, const long* len, int B, int Tk, float* h_out, hipStream_t st);
 void prompt_ws_destroy(Context& c);
+
+// audio.hip
+void audio_ws_destroy(Context& c);
 
 }  // namespace jv
 

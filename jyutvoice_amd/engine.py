@@ -131,6 +131,20 @@ class Engine:
                                     float(temperature), ts, _ptr(mel), _stream(self.device)))
         return mel
 
+    # ---- prompt mel front-end --------------------------------------------------------------------------
+    def load_mel_basis(self, basis: torch.Tensor):
+        t = basis.detach().to("cpu", torch.float32).contiguous()
+        check(self.lib.jv_load_mel_basis(self._h, t.data_ptr(), t.numel(), 0, _stream(self.device)))
+
+    def mel_spectrogram(self, wav):
+        """utils/audio.py:18-63 with extract_speech_feat's parameters: wav [B, n] -> log-mel [B, 80, 1 + (n - 480) // 480]"""
+        w = _f32(wav, self.device)
+        B, n = w.shape
+        T = 1 + (n - 480) // 480
+        mel = torch.empty(B, spec.N_FEATS, max(T, 0), device=self.device)
+        check(self.lib.jv_mel_spectrogram(self._h, _ptr(w), B, n, _ptr(mel), _stream(self.device)))
+        return mel
+
     # ---- prompt branch --------------------------------------------------------------------------------
     def prompt_encoder(self, token, token_len):
         """FlowEncoder.forward (infer.py:66-83): token [B,Tk] int64, token_len [B] -> prompt_h [B, 2*Tk, 80]"""

@@ -308,6 +308,28 @@ def main():
         g11["tok_" + tag], g11["h_" + tag] = tok, hr
     save("G11_prompt", **g11)
 
+    # ---- G12: prompt mel -- the reference's own mel_spectrogram (utils/audio.py:18-63) with extract_speech_feat's
+    # parameters (infer.py:166-186).  utils/audio.py imports librosa (absent, unpinned) for the mel filterbank only; a stub
+    # module hands it the restated Slaney construction, so the fixture pins everything after the filterbank.
+    from oracle import audio as oaudio
+    librosa = types.ModuleType("librosa")
+    librosa.__path__ = []
+    lf = types.ModuleType("librosa.filters")
+    lf.mel = lambda sr, n_fft, n_mels, fmin, fmax: oaudio.mel_basis_slaney(sr, n_fft, n_mels, fmin, fmax).numpy()
+    sys.modules["librosa"], sys.modules["librosa.filters"] = librosa, lf
+    from jyutvoice.utils.audio import mel_spectrogram as ref_mel
+    g = torch.Generator().manual_seed(12)
+    n = 24000 + 333                                         # not a multiple of the hop
+    tt = torch.arange(n) / 24000.0
+    wav12 = (0.3 * torch.sin(2 * np.pi * 220.0 * tt) + 0.2 * torch.sin(2 * np.pi * 1760.0 * tt + 1.0) +
+             0.1 * torch.sin(2 * np.pi * (300.0 + 2000.0 * tt) * tt) + 0.03 * torch.randn(n, generator=g)).unsqueeze(0)
+    mel_r = ref_mel(wav12, 1920, 80, 24000, 480, 1920, 0, 8000, center=False)
+    basis = oaudio.mel_basis_slaney()
+    report["G12 prompt mel"] = maxdiff(mel_r, oaudio.mel_spectrogram(wav12, basis))
+    feat, flen = oaudio.extract_speech_feat(wav12, basis)
+    assert feat.shape == (1, mel_r.shape[2], 80) and int(flen[0]) == mel_r.shape[2]
+    save("G12_prompt_mel", wav=wav12, mel=mel_r, basis_sum=basis.double().sum(), basis_rowmax=basis.max(dim=1).values)
+
     # ---- G6: padded batch equals per-utterance calls ---------------------------------------------
     o0 = est(xin[:1], mask[:1], mu[:1], t[:1], spks[:1], cond[:1])
     o1 = est(xin[1:, :, :20], mask[1:, :, :20], mu[1:, :, :20], t[1:], spks[1:], cond[1:, :, :20])

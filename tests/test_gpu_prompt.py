@@ -138,3 +138,28 @@ def test_cli_with_voice_prompt(tmp_path):
     out = tmp_path / "p.wav"
     infer.main(["--output", str(out), "--synthetic", "20", "--synthetic-prompt", "10", "--n_timesteps", "2"])
     assert out.stat().st_size > 44 + 2 * 480 * 10
+
+
+def test_prompt_mel_golden():
+    """GPU mel front-end (jv_mel_spectrogram) against the reference's utils/audio.py output (G12) and, on a batch and an
+    odd length, against the oracle.  Log-mel of a signal with a noise floor: the direct fp32 DFT and torch's FFT agree to
+    1e-5 in the log domain"""
+    from jyutvoice_amd.utils.audio import extract_speech_feat, mel_spectrogram
+    from oracle import audio as oaudio
+    g = load_golden("G12_prompt_mel")
+    mel = mel_spectrogram(g["wav"])
+    assert mel.shape == (1, 80, 50)
+    assert md(mel, g["mel"]) <= 5e-5                           # measured 8e-6
+    feat, n = extract_speech_feat(g["wav"])
+    assert feat.shape == (1, 50, 80) and int(n[0]) == 50 and md(feat.transpose(1, 2), g["mel"]) <= 5e-5
+    gen = torch.Generator().manual_seed(7)
+    wav = (torch.randn(3, 9000, generator=gen) * 0.2).clamp(-1, 1)
+    want = oaudio.mel_spectrogram(wav, oaudio.mel_basis_slaney())
+    got = mel_spectrogram(wav)
+    assert got.shape == want.shape == (3, 80, 1 + (9000 - 480) // 480)
+    assert md(got, want) <= 2e-4
+    with pytest.raises(NotImplementedError):
+        mel_spectrogram(wav, n_fft=1024)
+    from jyutvoice_amd._lib import JvError
+    with pytest.raises(JvError):
+        mel_spectrogram(torch.zeros(1, 500))

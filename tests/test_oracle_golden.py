@@ -138,3 +138,19 @@ def test_prompt_encoder(prompt_sd):
     for i in range(T):
         for j in range(T):
             assert float(y[0, 0, i, j]) == float(x[0, 0, i, j - i + T - 1])
+
+
+def test_prompt_mel():
+    """mel_spectrogram / extract_speech_feat restatement against the reference's utils/audio.py run on the same (restated,
+    librosa-style) filterbank; and the filterbank's own known answers: Slaney area normalisation, band layout"""
+    from oracle import audio as oaudio
+    g = load_golden("G12_prompt_mel")
+    basis = oaudio.mel_basis_slaney()
+    assert basis.shape == (80, 961)
+    assert abs(float(basis.double().sum()) - float(g["basis_sum"])) < 1e-9 and torch.equal(basis.max(dim=1).values, g["basis_rowmax"])
+    peak = basis.argmax(dim=1)
+    assert bool((peak[1:] > peak[:-1]).all()) and int(peak[-1]) * 12.5 < 8000 and float(basis[:, 641:].abs().max()) == 0.0
+    mel = oaudio.mel_spectrogram(g["wav"], basis)
+    assert md(mel, g["mel"]) <= 1e-6
+    feat, n = oaudio.extract_speech_feat(g["wav"], basis)
+    assert feat.shape == (1, 50, 80) and int(n[0]) == 50
