@@ -20,7 +20,8 @@ CSRC = os.path.join(HERE, "csrc")
 TAG = os.environ.get("JV_BUILD_TAG", "")
 OBJ = os.path.join(CSRC, "build", TAG) if TAG else os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, f"libjyutvoice_hip.{TAG}.so" if TAG else "libjyutvoice_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+# -fno-slp-vectorize: packed f32 VALU (v_pk_add/mul/fma_f32) issues slower than the scalar pair beside MFMAs on gfx950
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result", "-fno-slp-vectorize"]
 FLAGS += os.environ.get("JV_EXTRA_FLAGS", "").split()
 if os.environ.get("JV_TUNING"):      # ablation switches + in-kernel stamps (tools/gemm_bench.py); use with --force
     FLAGS.append("-DJV_TUNING")
