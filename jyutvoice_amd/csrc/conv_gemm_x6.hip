@@ -36,17 +36,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int ROWB = 64;      // bytes per LDS row: 32 bf16, 16-byte slots swizzled
 
 __device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
-  bf16x8 hh, mm, ll;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    hh[e] = (__bf16)x[e];
-    const float r = x[e] - (float)hh[e];
-    mm[e] = (__bf16)r;
-    ll[e] = (__bf16)(r - (float)mm[e]);
+  for (int e = 0; e < 4; ++e) {          // pair-wise: one v_cvt_pk_bf16_f32 per plane and pair
+    const Split3 t = split3_pair(x[2 * e], x[2 * e + 1]);
+    h[e] = t.h;
+    m[e] = t.m;
+    l[e] = t.l;
   }
-  h = __builtin_bit_cast(u32x4, hh);
-  m = __builtin_bit_cast(u32x4, mm);
-  l = __builtin_bit_cast(u32x4, ll);
 }
 
 // The 64x64 plain variants are held to 96 registers so five workgroups fit a CU: the N = 256 GEMMs of the estimator
