@@ -246,11 +246,13 @@ size_t x6_lds_bytes(const ConvGemmArgs& a, int nwb = 1) {
 
 template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int NWB>
 int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
-  static bool raised = false;
-  if (!raised) {
+  static bool raised[64] = {};      // per device: the attribute belongs to the kernel's image on the current device
+  int dev = 0;
+  JV_HIP(hipGetDevice(&dev));
+  if (!raised[dev & 63]) {
     JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, NWB>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    raised = true;
+    raised[dev & 63] = true;
   }
   size_t lds = x6_lds_bytes<BM, BN>(a, NWB);
   const size_t need = (size_t)4 * 32 * (WN + 4) * sizeof(float);
