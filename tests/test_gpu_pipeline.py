@@ -168,3 +168,34 @@ def test_load_errors(tts_sd):
         tts.load_state_dict(bad)
     with pytest.raises(FileNotFoundError):
         tts.load_pretrain("/nonexistent/pretrain.pt")
+
+
+def test_full_size_batch_invariance(models):
+    """BASELINE.json's headline shape (32 utterances x 150 tokens -> 300 frames), where the oracle takes minutes: the
+    size-independent properties instead -- every utterance of the batch equals its own single-utterance run (mel, vocoder
+    output with the same source), lengths are exact, padding stays zero, everything is finite and inside the audio limit"""
+    from jyutvoice_amd import synth
+    tts, hift = models
+    sd = synth.tts_state_dict(fixed_duration=1.5)
+    tts.load_state_dict(sd)
+    try:
+        B, Tt = 32, 150
+        b = synth.batch(B, Tt)
+        args = lambda sl: [b[k][sl] for k in ("x", "x_lengths", "lang", "tone", "word_pos", "syllable_pos", "spk_embed")] + [None]
+        res = tts.synthesise(*args(slice(0, B)), n_timesteps=3, batched=True)
+        assert res["mel"].shape == (B, 80, 2 * Tt) and res["mel_lengths"].tolist() == [2 * Tt] * B
+        assert torch.isfinite(res["mel"]).all()
+        attn = res["attn"]
+        assert attn.shape[-2:] == (Tt, 2 * Tt) and float(attn.sum()) == B * 2 * Tt          # one token per frame, exactly
+        f0 = hift._engine(B, 2 * Tt).hift_f0(res["mel"], None)
+        g = torch.Generator(device="cuda:0").manual_seed(5)
+        s = torch.randn(B, 1, 480 * 2 * Tt, device="cuda:0", generator=g) * 0.01
+        wav = hift.decode(res["mel"], s)
+        assert wav.shape == (B, 480 * 2 * Tt) and torch.isfinite(wav).all() and float(wav.abs().max()) <= 0.99 + 1e-6
+        for i in (0, 17, 31):
+            one = tts.synthesise(*args(slice(i, i + 1)), n_timesteps=3)
+            assert md(one["mel"], res["mel"][i:i + 1]) <= 2e-5, i                        # same kernels, other tile occupancy
+            assert md(hift._engine(1, 2 * Tt).hift_f0(one["mel"], None), f0[i:i + 1]) <= 1e-2
+            assert rms(hift.decode(one["mel"], s[i:i + 1]), wav[i:i + 1]) <= 2e-5, i
+    finally:
+        tts.load_state_dict(synth.tts_state_dict())
