@@ -11,7 +11,7 @@
 // Weights are split once at load time (registry.hip, three bf16 planes in HBM, 6 B per weight) and travel global -> LDS by
 // LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write); activations are split while the A window is staged
 // into LDS through registers (after the Snake / LeakyReLU / mask prologue), once per workgroup and K-chunk.
-// Both LDS images are unpadded 64-byte rows (32 bf16) whose 16-byte slots are XOR-swizzled with (row >> 2) & 3 -- for W on
+// Both LDS images are unpadded 64-byte rows (32 bf16) whose 16-byte slots are XOR-swizzled with swz(row) -- for W on
 // the SOURCE address, since the DMA writes lane-linear -- which keeps every ds_read_b128 lane group (8 consecutive k of
 // one row per lane) on 64 distinct banks.  Everything outside the main loop (tile order, masks, epilogue) is shared with
 // conv_gemm.hip.
@@ -34,6 +34,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROWB = 64;      // bytes per LDS row: 32 bf16, 16-byte slots swizzled
+
+// Slot key of a row.  (row >> 2) & 3 separates the rows that share a 64-byte quadrant of the 256-byte bank row inside every
+// ds_read_b128 lane group; the (row >> 1) & 1 term separates rows r and r + 2 inside the 8-lane groups of ds_write_b128,
+// whose bank period is 128 bytes (without it every A-plane store was a 2-way conflict: SQ_LDS_BANK_CONFLICT 25 %).
+__device__ __forceinline__ int swz(int row) { return ((row >> 2) & 3) ^ ((row >> 1) & 1); }
 
 __device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
 #pragma unroll
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
           }
           u32x4 h, m, l;
           split3x8(x, h, m, l);
-          unsigned char* dst = ldsA + r * ROWB + (((2 * khalf + g) ^ ((r >> 2) & 3)) << 4);
+          unsigned char* dst = ldsA + r * ROWB + (((2 * khalf + g) ^ swz(r)) << 4);
           *reinterpret_cast<u32x4*>(dst) = h;
           *reinterpret_cast<u32x4*>(dst + win * ROWB) = m;
           *reinterpret_cast<u32x4*>(dst + 2 * win * ROWB) = l;
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
       const int pc = wave + 4 * i;
       const int plane = pc / (BN / 16), g16 = pc % (BN / 16);
       const int row = g16 * 16 + (lane >> 2);
-      const int kslot = (lane & 3) ^ ((row >> 2) & 3);
+      const int kslot = (lane & 3) ^ swz(row);
       const int n = min(n0 + row, p.n_rows_w - 1);      // rows past the weight matrix feed columns that are never stored
       const unsigned short* src = p.W3 + (long)plane * p.w3_plane + (long)n * p.ldw + kb + 8 * kslot;
       unsigned char* dst = ldsW + ((buf * 3 + plane) * BN + g16 * 16) * ROWB;      // wave-uniform; the DMA adds lane * 16
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
     const unsigned char* la = ldsA + (wm * WM + r32 + j * dil) * ROWB;
     const unsigned char* lw = ldsW + (NWB == 2 ? (s & 1) * 3 * BN * ROWB : 0) + (wn * WN + r32) * ROWB;
     // WM, WN and the 32-row fragment steps are multiples of 16 rows, so only r32 (and the tap's row offset) enter the keys
-    const int swzw = (r32 >> 2) & 3, swza = ((r32 + j * dil) >> 2) & 3;
+    const int swzw = swz(r32), swza = swz(r32 + j * dil);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {            // two k-steps of 16 per 32-channel chunk
       bf16x8 a[MT][3], b[NT][3];
