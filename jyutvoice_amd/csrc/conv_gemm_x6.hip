@@ -38,6 +38,8 @@ constexpr int ROWB = 64;      // bytes per LDS row: 32 bf16, 16-byte slots swizz
 // Slot key of a row.  (row >> 2) & 3 separates the rows that share a 64-byte quadrant of the 256-byte bank row inside every
 // ds_read_b128 lane group; the (row >> 1) & 1 term separates rows r and r + 2 inside the 8-lane groups of ds_write_b128,
 // whose bank period is 128 bytes (without it every A-plane store was a 2-way conflict: SQ_LDS_BANK_CONFLICT 25 %).
+__device__ __attribute__((aligned(64))) const float jv_zero_page[16] = {};
+
 __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 3) ^ ((row >> 1) & 1); }
 
 __device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
@@ -86,26 +88,29 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
   unsigned char* const ldsA = reinterpret_cast<unsigned char*>(smem);            // [3][win][64 B]
   unsigned char* const ldsW = ldsA + 3 * win * ROWB;                             // [NWB][3][BN][64 B]
 
-  unsigned avalid = 0;
+  // Rows outside the matrix or masked out read as zero.  Instead of predicating every load of the loop (exec-mask
+  // branches, ~16 scalar instructions per step), such a row's pointer is aimed once at a page of zeros and its per-step
+  // advance set to 0: the loop body is branch-free.
+  const float* asrc[NA2];
+  int astep[NA2];
 #pragma unroll
   for (int i = 0; i < NA2; ++i) {
     const int r = arow + 128 * i;
     const long ar = (long)m0 + p.tap_row0 + r;
     bool ok = (r < win) && (ar >= 0) && (ar < p.a_rows);
     if (ok && p.rowmask_in) ok = p.rowmask_in[ar] != 0;
-    avalid |= ok ? (1u << i) : 0u;
+    asrc[i] = ok ? A + ar * p.lda + 16 * khalf : jv_zero_page;
+    astep[i] = ok ? 1 : 0;
   }
 
   f32x4 pa[NA2][4];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   auto load_A = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < NA2; ++i) {
-      const long ar = (long)m0 + p.tap_row0 + arow + 128 * i;
-      const float* src = A + ar * p.lda + c0 + 16 * khalf;
+      const float* src = asrc[i] + c0 * astep[i];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) pa[i][v] = ((avalid >> i) & 1u) ? *reinterpret_cast<const f32x4*>(src + 4 * v) : zero4;
+      for (int v = 0; v < 4; ++v) pa[i][v] = *reinterpret_cast<const f32x4*>(src + 4 * v);
     }
   };
   auto store_A = [&](int c0) {
