@@ -179,7 +179,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int AK_ROWB = 144, AV_ROWB = 80;
+constexpr int AK_ROWB = 144, AV_ROWB = 80;          // padded rows of the fp32-MFMA kernel's tiles
+// bf16x6 kernel: unpadded tiles [3 planes][32 keys][128 B] and [3][64 d][64 B]; slot keys: a ds_read_b128 lane group
+// holds every key parity twice per value of (key >> 1) & 7, and every 64-byte quadrant once per value of (row >> 2) & 3
+constexpr int XK_TILE = 3 * 32 * 128, XV_TILE = 3 * 64 * 64;
+__device__ __forceinline__ int xk_swz(int key) { return (key >> 1) & 7; }
+__device__ __forceinline__ int xv_swz(int row) { return (row >> 2) & 3; }
 
 // x -> (h, m, l) bf16 with x ~= h + m + l to 24 bits; a macro because vector elements cannot bind to references
 #define JV_SPLIT3(x, H, M, L)                 \
@@ -217,8 +222,10 @@ __device__ __forceinline__ f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[
 
 template <int NW, int WPE>
 __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char ldsK[3 * 32 * AK_ROWB];
-  __shared__ __attribute__((aligned(16))) unsigned char ldsV[3 * 64 * AV_ROWB];
+  // Two buffers per operand, one barrier per key tile: tile kt + 1 is split and stored into the other buffer while tile kt
+  // is being used.  Rows are unpadded (K: 128 B = 64 d, V^T: 64 B = 32 keys) with XOR-swizzled 16-byte slots, which keeps
+  // the ds_read_b128 fragment fetches conflict-free and the two buffers within 48 KiB (three workgroups per CU).
+  __shared__ __attribute__((aligned(256))) unsigned char ldsKV[2 * (XK_TILE + XV_TILE)];
   constexpr int NT = 64 * NW;
   constexpr int NKL = (32 * 16 + NT - 1) / NT;   // f32x4 pieces of K per thread per tile (512 pieces over the workgroup)
   constexpr int NVG = (8 + NW - 1) / NW;         // groups of 4 consecutive keys of V per thread per tile (8 groups over the waves)
@@ -307,11 +314,9 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
     kmax = min(len, ((qt * 32 * NW + 32 * NW - 1) / p.chunk + 1) * p.chunk);
   }
   const int nkt = (kmax + 31) >> 5;
-  if (nkt > 0) prefetch(0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int k0 = kt * 32;
-    if (!JV_ABLATE(p, 4)) __syncthreads();
-    if (!JV_ABLATE(p, 2)) {
+  auto stage = [&](int buf) {      // split the prefetched K / V tile into the three bf16 planes of buffer `buf`
+    unsigned char* const bK = ldsKV + buf * (XK_TILE + XV_TILE);
+    unsigned char* const bV = bK + XK_TILE;
 #pragma unroll
     for (int i = 0; i < NKL; ++i) {
       const int idx = tid + i * NT;
@@ -320,40 +325,53 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
       u32x2 hh, mm, ll;
       { const Split3 t_ = split3_pair(pk[i][0], pk[i][1]); hh[0] = t_.h; mm[0] = t_.m; ll[0] = t_.l; }
       { const Split3 t_ = split3_pair(pk[i][2], pk[i][3]); hh[1] = t_.h; mm[1] = t_.m; ll[1] = t_.l; }
-      unsigned char* dst = ldsK + key * AK_ROWB + c4 * 8;
+      unsigned char* dst = bK + key * 128 + ((((c4 >> 1) ^ xk_swz(key)) << 4) | ((c4 & 1) << 3));
       *reinterpret_cast<u32x2*>(dst) = hh;
-      *reinterpret_cast<u32x2*>(dst + 32 * AK_ROWB) = mm;
-      *reinterpret_cast<u32x2*>(dst + 64 * AK_ROWB) = ll;
+      *reinterpret_cast<u32x2*>(dst + 32 * 128) = mm;
+      *reinterpret_cast<u32x2*>(dst + 64 * 128) = ll;
     }
 #pragma unroll
     for (int j = 0; j < NVG; ++j) {             // 4 consecutive keys stay consecutive under the bit swap
       const int g = vkg + j * NW;
       if ((8 % NW) != 0 && g >= 8) continue;
       const int key = 4 * g;
-      const int pos = (key & 0x13) | ((key & 4) << 1) | ((key & 8) >> 1);
+      const int pos = (key & 0x13) | ((key & 4) << 1) | ((key & 8) >> 1);       // bf16 index inside the 32-key row
       u32x2 hh, mm, ll;
       { const Split3 t_ = split3_pair(pv[j][0], pv[j][1]); hh[0] = t_.h; mm[0] = t_.m; ll[0] = t_.l; }
       { const Split3 t_ = split3_pair(pv[j][2], pv[j][3]); hh[1] = t_.h; mm[1] = t_.m; ll[1] = t_.l; }
-      unsigned char* dst = ldsV + vd * AV_ROWB + pos * 2;
+      unsigned char* dst = bV + vd * 64 + ((((pos >> 3) ^ xv_swz(vd)) << 4) | (((pos >> 2) & 1) << 3));
       *reinterpret_cast<u32x2*>(dst) = hh;
-      *reinterpret_cast<u32x2*>(dst + 64 * AV_ROWB) = mm;
-      *reinterpret_cast<u32x2*>(dst + 128 * AV_ROWB) = ll;
+      *reinterpret_cast<u32x2*>(dst + 64 * 64) = mm;
+      *reinterpret_cast<u32x2*>(dst + 128 * 64) = ll;
     }
+  };
+  if (nkt > 0) {
+    prefetch(0);
+    stage(0);
+    if (nkt > 1) prefetch(32);
+    __syncthreads();
+  }
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int k0 = kt * 32;
+    // buffer kt & 1 holds tile kt (stored before the previous barrier); registers hold tile kt + 1
+    if (kt + 1 < nkt) {
+      stage((kt + 1) & 1);                      // that buffer was last read in iteration kt - 1, before the barrier
+      if (kt + 2 < nkt) prefetch(k0 + 64);
     }
-    if (!JV_ABLATE(p, 4)) __syncthreads();
-    if (kt + 1 < nkt && !JV_ABLATE(p, 1)) prefetch(k0 + 32);
-    if (!active) continue;
-
+    const unsigned char* const ldsK = ldsKV + (kt & 1) * (XK_TILE + XV_TILE);
+    const unsigned char* const ldsV = ldsK + XK_TILE;
+    if (active) {
     // S^T[key][query] = sum_d K[key][d] * Q[query][d]
     f32x16 s;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = 0.f;
-    const unsigned char* kr = ldsK + r32 * AK_ROWB + 16 * half;
+    const unsigned char* kr = ldsK + r32 * 128;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       bf16x8 a[3];
+      const int ko = ((2 * st + half) ^ xk_swz(r32)) << 4;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(kr + pl * 32 * AK_ROWB + 32 * st);
+      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(kr + pl * 32 * 128 + ko);
       if (!JV_ABLATE(p, 16)) s = mfma6(a, q[st], s);
       else s[st] += (float)a[0][0] + (float)a[1][1] + (float)a[2][2];
     }
@@ -388,7 +406,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
     }
     }
     // O^T[d][query] += sum_key V[key][d] * P[query][key]
-    const unsigned char* vr = ldsV + r32 * AV_ROWB + 16 * half;
+    const unsigned char* vr = ldsV + r32 * 64;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       u32x4 ph, pm, pl_;
@@ -396,15 +414,19 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
       for (int e = 0; e < 4; ++e) { const Split3 t_ = split3_pair(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]); ph[e] = t_.h; pm[e] = t_.m; pl_[e] = t_.l; }
       const bf16x8 pb[3] = {__builtin_bit_cast(bf16x8, ph), __builtin_bit_cast(bf16x8, pm), __builtin_bit_cast(bf16x8, pl_)};
       bf16x8 a[3];
+      const int vo = ((2 * st + half) ^ xv_swz(r32)) << 4;       // rows r32 and r32 + 32 share the key
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(vr + pl * 64 * AV_ROWB + 32 * st);
+      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(vr + pl * 64 * 64 + vo);
       if (!JV_ABLATE(p, 8)) o0 = mfma6(a, pb, o0);
       else o0[st] += (float)a[0][0] + (float)a[1][1] + (float)a[2][2] + (float)pb[0][0] + (float)pb[1][1] + (float)pb[2][2];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(vr + (pl * 64 + 32) * AV_ROWB + 32 * st);
+      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(vr + (pl * 64 + 32) * 64 + vo);
       if (!JV_ABLATE(p, 8)) o1 = mfma6(a, pb, o1);
       else o1[st] += (float)a[0][0] + (float)a[1][1] + (float)a[2][2];
     }
+    }
+    // the one barrier of the tile: tile kt + 1 is complete in the other buffer, and nobody reads this one any more
+    if (!JV_ABLATE(p, 4)) __syncthreads();
   }
 
   const int qi = q0 + r32;
