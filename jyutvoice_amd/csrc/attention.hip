@@ -170,8 +170,8 @@ __global__ __launch_bounds__(64 * NW) void attn64_kernel(const AttnArgs p) {
 }
 
 // ---- bf16x6 variant: same algorithm, contractions as six bf16 MFMA products of 3-plane splits (conv_gemm_x6.hip) -----
-// K is split while it is staged ([3][32 keys][64 d], 144-byte rows); V is split AND transposed to [3][64 d][32 keys]
-// (80-byte rows) so that the PV product's A operand is 8 consecutive keys of one d; the key order inside a tile is the
+// K is split while it is staged ([3][32 keys][64 d]); V is split AND transposed to [3][64 d][32 keys] so that the PV
+// product's A operand is 8 consecutive keys of one d; the key order inside a tile is the
 // one the S^T accumulator already has (register e of lane-half h holds key (e&3)+8(e>>2)+4h), i.e. position p in the V^T
 // row holds key swap_bits23(p): P goes from the softmax to the MFMA with three conversions and no data movement.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -179,24 +179,11 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int AK_ROWB = 144, AV_ROWB = 80;          // padded rows of the fp32-MFMA kernel's tiles
 // bf16x6 kernel: unpadded tiles [3 planes][32 keys][128 B] and [3][64 d][64 B]; slot keys: a ds_read_b128 lane group
 // holds every key parity twice per value of (key >> 1) & 7, and every 64-byte quadrant once per value of (row >> 2) & 3
 constexpr int XK_TILE = 3 * 32 * 128, XV_TILE = 3 * 64 * 64;
 __device__ __forceinline__ int xk_swz(int key) { return (key >> 1) & 7; }
 __device__ __forceinline__ int xv_swz(int row) { return (row >> 2) & 3; }
-
-// x -> (h, m, l) bf16 with x ~= h + m + l to 24 bits; a macro because vector elements cannot bind to references
-#define JV_SPLIT3(x, H, M, L)                 \
-  do {                                        \
-    const float _x = (x);                     \
-    const __bf16 _h = (__bf16)_x;             \
-    const float _r = _x - (float)_h;          \
-    const __bf16 _m = (__bf16)_r;             \
-    (H) = _h;                                 \
-    (M) = _m;                                 \
-    (L) = (__bf16)(_r - (float)_m);           \
-  } while (0)
 
 // combine a value with its partner lane's (lane ^ 32: the two lanes that hold one query's keys) in one VALU op:
 // v_permlane32_swap_b32 (gfx950) returns {own half | partner's low half, partner's high half | own}; ds_bpermute, what
