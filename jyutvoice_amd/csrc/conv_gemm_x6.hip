@@ -343,8 +343,7 @@ int x6_launch1(const ConvGemmArgs& a, hipStream_t st) {
   if (lean && a.act == ACT_NONE)
     return a.res1 ? x6_launch2<BM, BN, WM, WN, PRO, 2>(a, st) : x6_launch2<BM, BN, WM, WN, PRO, 0>(a, st);
   if (lean && a.act == ACT_GELU && PRO == PRO_NONE && !a.res1) return x6_launch2<BM, BN, WM, WN, PRO_NONE, 1>(a, st);
-  if constexpr (WM > 64) return fail(JV_ERR_ARG, "conv_gemm_x6: this tile variant has no generic epilogue");
-  else return x6_launch2<BM, BN, WM, WN, PRO, 4>(a, st);
+  return x6_launch2<BM, BN, WM, WN, PRO, 4>(a, st);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -365,9 +364,7 @@ int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st) {
   struct Cand { int bm, bn; double eff; size_t lds; int max_win; };
   // measured on the estimator shapes (tools/gemm_bench.py): the big tile amortises staging and barriers best.  The
   // 160-row tile (each wave 160 x 32) exists for the workgroup-round arithmetic: M = 19.5K rows x N = 1024 is 2.4 rounds
-  // of 128 x 128 tiles over 512 slots (3 to wait for) but 1.9 rounds of 160 x 128 ones; it has no generic epilogue.
-  const bool lean = !(a.N & 3) && !(a.ldo & 3) && (!a.res1 || !(a.ldr1 & 3)) && !a.res2 && !a.rowvec && !a.rowmask_out &&
-                    !a.accumulate && a.out_scale == 1.f && (a.act == ACT_NONE || (a.act == ACT_GELU && a.pro == PRO_NONE && !a.res1));
+  // of 128 x 128 tiles over 512 slots (3 to wait for) but 1.9 rounds of 160 x 128 ones.
   const Cand cands[5] = {{128, 128, 1.0, x6_lds_bytes<128, 128>(a), 256}, {64, 128, 0.8, x6_lds_bytes<64, 128>(a), 128},
                          {64, 64, 0.8, x6_lds_bytes<64, 64>(a), 128}, {160, 128, 0.97, x6_lds_bytes<160, 128>(a), 256},
                          {128, 64, 0.9, x6_lds_bytes<128, 64>(a), 256}};
@@ -385,7 +382,7 @@ int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st) {
   if (best == 2 && a.N <= 64 && a.M >= 128 * 512 && cands[4].bm + span <= cands[4].max_win && cands[4].lds <= 80 * 1024 &&
       !dyn_env("JV_NO_T128x64"))
     best = 4;
-  if (best == 0 && lean && cands[3].bm + span <= cands[3].max_win && !dyn_env("JV_NO_T160")) {
+  if (best == 0 && cands[3].bm + span <= cands[3].max_win && !dyn_env("JV_NO_T160")) {
     // both run two workgroups per CU: rounds of 512 resident tiles x rows per tile
     const long r128 = cdivl((long)cdiv(a.M, 128) * cdiv(a.N, 128), 512) * 128;
     const long r160 = cdivl((long)cdiv(a.M, 160) * cdiv(a.N, 128), 512) * 160;
@@ -393,7 +390,7 @@ int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st) {
   }
   if (const char* force = dyn_env("JV_TILE")) {
     const int f = atoi(force);
-    if (f >= 0 && f <= 4 && cands[f].bm + span <= cands[f].max_win && (f != 3 || lean)) best = f;
+    if (f >= 0 && f <= 4 && cands[f].bm + span <= cands[f].max_win) best = f;
   }
   switch (best) {
     case 0: return x6_launch<128, 128, 64, 64>(a, st);
