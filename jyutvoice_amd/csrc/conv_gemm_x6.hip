@@ -54,7 +54,8 @@ __device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& h, u32x4& m
 
 // The 64x64 plain variants are held to 96 registers so five workgroups fit a CU: the N = 256 GEMMs of the estimator
 // make 1220 such tiles, which then all run in one resident wave (1280 slots) instead of 1024 + a 20 % tail.
-// NA2: window rows staged per thread (rows tid>>1 + 128 i): 1 when the A window fits 128 rows, else 2.
+// NA2: window rows staged per thread (rows tid>>1 + 128 i, 16 k each): 1 when the A window fits 128 rows, else 2; 0 when it
+// fits 64 rows: four threads per row, 8 k each, so that all four waves share the split instead of two doing all of it.
 // NWB: weight buffers in LDS.  2: the DMA for step s + 1 is issued behind step s's barriers and lands during its MFMAs;
 // 1: the DMA is issued between the two barriers of its own step and lands while the wave splits and stores its A rows.
 template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int NWB>
@@ -68,7 +69,10 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int r32 = lane & 31, half = lane >> 5;
-  const int arow = tid >> 1, khalf = tid & 1;
+  constexpr bool AQ = NA2 == 0;                  // quarter-row staging
+  constexpr int NR = AQ ? 1 : NA2, NG = AQ ? 1 : 2;
+  const int arow = AQ ? tid >> 2 : tid >> 1, kpart = AQ ? tid & 3 : tid & 1;
+  const int koff = (AQ ? 8 : 16) * kpart;
 
   int m0, n0;
   {
@@ -91,40 +95,40 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
   // Rows outside the matrix or masked out read as zero.  Instead of predicating every load of the loop (exec-mask
   // branches, ~16 scalar instructions per step), such a row's pointer is aimed once at a page of zeros and its per-step
   // advance set to 0: the loop body is branch-free.
-  const float* asrc[NA2];
-  int astep[NA2];
+  const float* asrc[NR];
+  int astep[NR];
 #pragma unroll
-  for (int i = 0; i < NA2; ++i) {
+  for (int i = 0; i < NR; ++i) {
     const int r = arow + 128 * i;
     const long ar = (long)m0 + p.tap_row0 + r;
     bool ok = (r < win) && (ar >= 0) && (ar < p.a_rows);
     if (ok && p.rowmask_in) ok = p.rowmask_in[ar] != 0;
-    asrc[i] = ok ? A + ar * p.lda + 16 * khalf : jv_zero_page;
+    asrc[i] = ok ? A + ar * p.lda + koff : jv_zero_page;
     astep[i] = ok ? 1 : 0;
   }
 
-  f32x4 pa[NA2][4];
+  f32x4 pa[NR][2 * NG];
 
   auto load_A = [&](int c0) {
 #pragma unroll
-    for (int i = 0; i < NA2; ++i) {
+    for (int i = 0; i < NR; ++i) {
       const float* src = asrc[i] + c0 * astep[i];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) pa[i][v] = *reinterpret_cast<const f32x4*>(src + 4 * v);
+      for (int v = 0; v < 2 * NG; ++v) pa[i][v] = *reinterpret_cast<const f32x4*>(src + 4 * v);
     }
   };
   auto store_A = [&](int c0) {
 #pragma unroll
-    for (int i = 0; i < NA2; ++i) {
+    for (int i = 0; i < NR; ++i) {
       const int r = arow + 128 * i;
       if (r < win) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {          // two groups of 8 consecutive k
+        for (int g = 0; g < NG; ++g) {         // groups of 8 consecutive k
           float x[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = pa[i][2 * g + (e >> 2)][e & 3];
           if (PRO == PRO_SNAKE) {
-            const float* al = p.pro_alpha + c0 + 16 * khalf + 8 * g;
+            const float* al = p.pro_alpha + c0 + koff + 8 * g;
             float arg[8], inv[8];
             bool big = false;
 #pragma unroll
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
           }
           u32x4 h, m, l;
           split3x8(x, h, m, l);
-          unsigned char* dst = ldsA + r * ROWB + (((2 * khalf + g) ^ swz(r)) << 4);
+          unsigned char* dst = ldsA + r * ROWB + ((((AQ ? kpart : 2 * kpart + g)) ^ swz(r)) << 4);
           *reinterpret_cast<u32x4*>(dst) = h;
           *reinterpret_cast<u32x4*>(dst + win * ROWB) = m;
           *reinterpret_cast<u32x4*>(dst + 2 * win * ROWB) = l;
@@ -331,8 +335,9 @@ int x6_launch2(const ConvGemmArgs& a, hipStream_t st) {
   } else {
     // Few tiles (small batches): occupancy cannot hide the weight DMA's latency, LDS is plentiful -> two W buffers
     const long tiles = (long)cdiv(a.M, BM) * cdiv(a.N, BN);
-    if (tiles <= 1024 && x6_lds_bytes<BM, BN>(a, 2) <= 64 * 1024) return x6_launch3<BM, BN, WM, WN, PRO, EPI, 1, 2>(a, st);
-    return x6_launch3<BM, BN, WM, WN, PRO, EPI, 1, 1>(a, st);
+    const bool two = tiles <= 1024 && x6_lds_bytes<BM, BN>(a, 2) <= 64 * 1024;
+    if (win <= 64) return two ? x6_launch3<BM, BN, WM, WN, PRO, EPI, 0, 2>(a, st) : x6_launch3<BM, BN, WM, WN, PRO, EPI, 0, 1>(a, st);
+    return two ? x6_launch3<BM, BN, WM, WN, PRO, EPI, 1, 2>(a, st) : x6_launch3<BM, BN, WM, WN, PRO, EPI, 1, 1>(a, st);
   }
 }
 
