@@ -137,7 +137,8 @@ def main():
     dev_index = local_rank % max(1, torch.cuda.device_count())   # one rank per GPU on the real node; the modulo only matters
     torch.cuda.set_device(dev_index)                             # when rehearsing several ranks on a 1-GPU box (gloo)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("JV_FORCE_DIST") == "1"   # JV_FORCE_DIST: run the collective path with one rank
+    if use_dist:
         backend = os.environ.get("JV_DIST_BACKEND", "nccl")      # nccl == RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -173,7 +174,7 @@ def main():
         res = tts.synthesise(batch["x"], batch["x_lengths"], batch["lang"], batch["tone"], batch["word_pos"],
                              batch["syllable_pos"], batch["spk_embed"], None, n_timesteps=n_steps, batched=True)
         wav, _ = hift.inference(res["mel"])
-        if world > 1:
+        if use_dist:
             jdist.all_gather_mels(res["mel"], res["mel_lengths"])
         return res, wav
 
@@ -182,7 +183,7 @@ def main():
 
     profile = not args.no_profile
     torch.cuda.synchronize(device)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     if profile:
         engine.profile_report()          # drop anything recorded during warm-up
@@ -195,7 +196,7 @@ def main():
             engine.profile_enable(False)     # events stay queued on the stream; read back after the timed region
         res, wav = step()
     torch.cuda.synchronize(device)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     assert res["mel"].shape == (B, 80, T) and torch.isfinite(res["mel"]).all(), res["mel"].shape
@@ -205,7 +206,7 @@ def main():
     if profile:
         engine.profile_enable(False)
         kern = engine.profile_report()
-    if world > 1:
+    if use_dist:
         el = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
@@ -256,7 +257,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "c3":
             out["cpu_baseline"] = cpu_baseline(Tt, n_steps, args.cpu_utts)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -82,6 +82,14 @@ int jv_flow_set_streaming(jv_context* ctx, int chunk_frames);
  * the GPU.  The in-library profiler (jv_profile_enable) forces the eager path because it brackets every
  * launch with events.  Results are bit-identical either way. */
 int jv_flow_set_graph(jv_context* ctx, int on);
+/* jv_flow_set_contraction: how the estimator's fp32 Linear layers (transformer.py:355-443: to_q/k/v, to_out, ff.net.0,
+ * ff.net.2 -- 4 x 56 GEMMs per call) are contracted on the matrix cores.  exact_range = 0 (default): fp16x3 -- each
+ * operand split into two fp16 planes after an exact power-of-two scaling (22 significant bits, three MFMA products,
+ * fp32 accumulate) -- on exactly those layers whose input range is PROVEN at load time from the weights (LayerNorm
+ * outputs, attention outputs, GELU of a bounded Linear); every other contraction, and all of them with exact_range = 1
+ * (or JV_EXACT_RANGE=1 in the environment at jv_create), runs bf16x6 (three bf16 planes, 24 bits, six products), which
+ * takes any fp32 operand.  Both meet the same operator-level bound against fp64 (tests/test_gpu_ops.py). */
+int jv_flow_set_contraction(jv_context* ctx, int exact_range);
 /* jv_cfm_solve: CausalConditionalCFM.forward + ConditionalCFM.solve_euler (flow_matching.py:356-401, 215-265):
  * fixed noise prefix * temperature, cosine schedule, n_timesteps Euler steps with CFG rate 0.7.
  * mu, cond, mel: [B,80,T]; spks: [B,80]; lens: [B] int32 or NULL.  t_span_host: optional n_timesteps+1 host floats
@@ -141,11 +149,15 @@ int jv_hift_decode(jv_context* ctx, const float* mel, const float* s, const int3
  * jv_op_conv_gemm: out[m,n] = act(sum_{j,ci} A[m + tap_row0 + j*dil, ci] * W[n, j*Cin + ci] + bias[n]) (+ res[m,n])
  *                  A [a_rows, Cin] rows, W [N, ntaps*Cin], optional LayerNorm over N (N == 256) before act.
  * jv_op_attention: softmax(q k^T / 8 over keys < lens[b]) v for qkv rows [G + b*S + t][1536], 8 heads x 64.
- * jv_op_layernorm: rows [rows, C]. */
+ * jv_op_layernorm: rows [rows, C].
+ * jv_op_linear_h3: out = act(A W^T + bias) (+ res) through the fp16x3 main loop (jv_flow_set_contraction); A [rows, K],
+ *                  W [N, K], a_bound = the caller's bound on |A| (the kernel's contract: |A| <= a_bound). */
 int jv_op_conv_gemm(const float* A, int64_t a_rows, int M, int Cin, int ntaps, int tap_row0, int dil, const float* W, int N,
                     const float* bias, int act, int prologue, const float* alpha, float slope, const float* ln_g,
                     const float* ln_b, float ln_eps, const uint8_t* rowmask, const float* res, float* out, void* stream);
 int jv_op_attention(const float* qkv, const int32_t* lens, int B, int G, int S, int L, float* out, void* stream);
+int jv_op_linear_h3(const float* A, int64_t rows, int M, int K, const float* W, int N, const float* bias, int act,
+                    const float* res, float a_bound, float* out, void* stream);
 int jv_op_layernorm(const float* x, const float* g, const float* b, float eps, int64_t rows, int C, float* out,
                     void* stream);
 

@@ -48,6 +48,7 @@ SIGNATURES = {
     "jv_flow_estimator_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
     "jv_flow_set_streaming": (_i, [_p, _i]),
     "jv_flow_set_graph": (_i, [_p, _i]),
+    "jv_flow_set_contraction": (_i, [_p, _i]),
     "jv_cfm_solve": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
     "jv_encoder_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
     "jv_load_mel_basis": (_i, [_p, _p, _i64, _i, _p]),
@@ -59,6 +60,7 @@ SIGNATURES = {
     "jv_hift_decode": (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
     "jv_op_conv_gemm": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _f, _p, _p, _f, _p, _p, _p, _p]),
     "jv_op_attention": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "jv_op_linear_h3": (_i, [_p, _i64, _i, _i, _p, _i, _p, _i, _p, _f, _p, _p]),
     "jv_op_layernorm": (_i, [_p, _p, _p, _f, _i64, _i, _p, _p]),
     "jv_profile_enable": (_i, [_i]),
     "jv_profile_report": (_i, [C.c_char_p, _i64]),

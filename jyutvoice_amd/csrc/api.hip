@@ -11,6 +11,8 @@
 namespace jv {
 
 int split3_planes(const float* src, unsigned short* dst, long n, hipStream_t st);   // registry.hip
+int split2h_planes(const float* src, int rows, int ld, float* stats, unsigned short* dst, float* colscale, hipStream_t st);
+float h3_scale_for_bound(float bound);
 
 static thread_local std::string g_last_error;
 
@@ -71,6 +73,7 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   c.device = device;
   c.max_batch = max_batch;
   c.step_graphs = getenv("JV_STEP_GRAPH") != nullptr;
+  c.exact_range = getenv("JV_EXACT_RANGE") != nullptr;
   c.max_frames = max_frames;
   c.max_tokens = max_tokens;
   jv::build_registry(c);
@@ -186,6 +189,13 @@ int jv_flow_set_graph(jv_context* ctx, int on) {
   return JV_OK;
 }
 
+int jv_flow_set_contraction(jv_context* ctx, int exact_range) {
+  if (!ctx) return jv::fail(JV_ERR_ARG, "null context");
+  if (ctx->c.exact_range != (exact_range != 0)) jv::flow_graphs_drop(ctx->c);      // captured steps hold the old kernels
+  ctx->c.exact_range = exact_range != 0;
+  return JV_OK;
+}
+
 int jv_cfm_solve(jv_context* ctx, const float* mu, const int32_t* lens, const float* spks, const float* cond, int B, int T,
                  int n_timesteps, float temperature, const float* t_span_host, float* mel, void* stream) {
   CTX_GUARD(ctx);
@@ -225,6 +235,39 @@ int jv_op_conv_gemm(const float* A, int64_t a_rows, int M, int Cin, int ntaps, i
     a.w3_plane = (long)n;
   }
   return jv::conv_gemm(a, 1, static_cast<hipStream_t>(stream));
+}
+
+// y = act(A W^T + bias) (+ res) through the fp16x3 main loop; a_bound: the caller's proven bound on |A| (test hook)
+int jv_op_linear_h3(const float* A, int64_t rows, int M, int K, const float* W, int N, const float* bias, int act,
+                    const float* res, float a_bound, float* out, void* stream) {
+  static bool inited = false;
+  if (!inited) {
+    JV_TRY(jv::conv_gemm_init());
+    inited = true;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (K % 32 || N <= 0 || M <= 0) return jv::fail(JV_ERR_ARG, "jv_op_linear_h3: K must be a multiple of 32");
+  const float sc = jv::h3_scale_for_bound(a_bound);
+  if (!(sc > 0.f)) return jv::fail(JV_ERR_ARG, "jv_op_linear_h3: unusable bound");
+  static void* scratch = nullptr;
+  static size_t cap = 0;
+  const size_t n = (size_t)N * K;
+  const size_t need = n * 4 + (size_t)N * 12 + 256;
+  if (need > cap) {
+    if (scratch) (void)hipFree(scratch);
+    JV_HIP(hipMalloc(&scratch, need));
+    cap = need;
+  }
+  unsigned short* planes = static_cast<unsigned short*>(scratch);
+  float* cs = reinterpret_cast<float*>(static_cast<char*>(scratch) + ((n * 4 + 63) & ~(size_t)63));
+  JV_TRY(jv::split2h_planes(W, N, K, cs + N, planes, cs, st));
+  jv::ConvGemmArgs a;
+  jv::conv_gemm_defaults(a);
+  a.A = A; a.lda = K; a.a_rows = rows; a.M = M; a.Cin = K; a.ntaps = 1; a.tap_row0 = 0; a.tap_dil = 1;
+  a.W = W; a.ldw = K; a.n_rows_w = N; a.N = N; a.bias = bias; a.out = out; a.ldo = N; a.act = act;
+  a.res1 = res; a.ldr1 = N;
+  a.W2 = planes; a.w2_plane = (long)n; a.colscale = cs; a.a_scale = sc;
+  return jv::conv_gemm(a, 1, st);
 }
 
 int jv_op_attention(const float* qkv, const int32_t* lens, int B, int G, int S, int L, float* out, void* stream) {

@@ -233,6 +233,7 @@ void conv_gemm_defaults(ConvGemmArgs& a) {
   a.ntaps = 1;
   a.tap_dil = 1;
   a.out_scale = 1.f;
+  a.a_scale = 1.f;
   a.nb2 = 1;
   a.ln_eps = 1e-5f;
 }
@@ -367,7 +368,7 @@ int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
                             a.rowvec_ld, a.res1, a.ldr1, a.out_scale, st);
   }
   if (const char* ab = tuning_env("JV_ABLATE")) const_cast<ConvGemmArgs&>(a).ablate = atoi(ab);
-  if (a.W3 && nbatch == 1 && (a.ldw & 7) == 0 && !dyn_env("JV_NO_X6")) return conv_gemm_x6(a, st);
+  if ((a.W3 || a.W2) && nbatch == 1 && (a.ldw & 7) == 0 && !dyn_env("JV_NO_X6")) return conv_gemm_x6(a, st);
   // Tile choice: the kernel is MFMA-bound, so cost ~ (#workgroup waves over 256 CUs) x tile area, with a mild penalty
   // for the smaller tiles' lower operand reuse; a variant must fit two workgroups' double-buffered LDS on a CU.
   const int span = (a.ntaps - 1) * a.tap_dil;

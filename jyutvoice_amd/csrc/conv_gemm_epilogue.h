@@ -25,7 +25,8 @@ __device__ __forceinline__ void epilogue_passes(F& f) {      // f(0), f(1), ... 
 // EPI: bit 0 = exact GELU, bit 1 = + res1 (lean float4 epilogues); 4 = generic (any activation, mask, row vector,
 // second residual, scaling, accumulation, ragged N).  Must be entered by all 256 threads after the main loop's last
 // barrier; `smem` is reused for the slabs.
-template <int WM, int WN, int EPI>
+// SC: the accumulators are first multiplied by colscale[n] / a_scale (fp16x3 main loop, ConvGemmArgs::W2).
+template <int WM, int WN, int EPI, bool SC = false>
 __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out, f32x16 (&acc)[WM / 32][WN / 32], float* smem,
                                               const int m0, const int n0, const int wm, const int wn,
                                               unsigned long long t_start, unsigned long long t_loop) {
@@ -54,6 +55,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
     else
       for (int e = 0; e < 4; ++e) bb[e] = (n + e < p.N) ? p.bias[n + e] : 0.f;
   }
+  f32x4 cs = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (SC) {
+    const float inv = 1.0f / p.a_scale;      // powers of two: exact
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[e] = (n + e < p.N) ? p.colscale[n + e] * inv : 0.f;
+  }
   auto pass = [&](auto mt_tag) {
     constexpr int mt = decltype(mt_tag)::value;
     // The slab is private to the wave and LDS executes one wave's accesses in program order: no barrier between a
@@ -80,7 +87,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
       float* ob = out + (long)mrow * p.ldo + n;
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        f32x4 t = x[it] + bb;
+        f32x4 t = SC ? x[it] * cs + bb : x[it] + bb;
         if constexpr (E_GELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) t[e] = 0.5f * t[e] * (1.f + erff(t[e] * 0.70710678118654752440f));
@@ -135,7 +142,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
         f32x4 res;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float t = act_apply(x[u][e] + bb[e], p.act);
+          float t = act_apply((SC ? x[u][e] * cs[e] : x[u][e]) + bb[e], p.act);
           if (!keep[u]) t = 0.f;
           t = ((t + rvv[e]) + r1[u][e]) + r2[u][e];
           res[e] = t * p.out_scale + pv[u][e];

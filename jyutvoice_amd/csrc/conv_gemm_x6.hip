@@ -31,6 +31,7 @@
 namespace jv {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROWB = 64;      // bytes per LDS row: 32 bf16, 16-byte slots swizzled
@@ -58,10 +59,14 @@ __device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& h, u32x4& m
 // fits 64 rows: four threads per row, 8 k each, so that all four waves share the split instead of two doing all of it.
 // NWB: weight buffers in LDS.  2: the DMA for step s + 1 is issued behind step s's barriers and lands during its MFMAs;
 // 1: the DMA is issued between the two barriers of its own step and lands while the wave splits and stores its A rows.
-template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int NWB>
+// NP: planes per operand.  3: bf16 (h, m, l), six products, any fp32 operand.  2: fp16 (h, l) of A * a_scale and of the
+// per-row scaled W (p.W2), three products h h' + h l' + l h' (dropped: l l', relative 2^-22) -- half the matrix-pipe,
+// LDS and DMA work for operands whose range a load-time bound has proven (ConvGemmArgs::W2).
+template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int NWB, int NP>
 __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EPI != 4) ? 5 : 2) void conv_gemm_x6_kernel(const ConvGemmArgs p, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = WM / 32, NT = WN / 32;
+  static_assert(NP == 3 || (NP == 2 && PRO == PRO_NONE), "fp16x3 takes plain operands only");
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
   static_assert(NWB == 1 || NWB == 2, "one or two weight buffers");
@@ -89,8 +94,8 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
 
   const int ntaps = p.ntaps, dil = p.tap_dil;
   const int win = BM + (ntaps - 1) * dil;
-  unsigned char* const ldsA = reinterpret_cast<unsigned char*>(smem);            // [3][win][64 B]
-  unsigned char* const ldsW = ldsA + 3 * win * ROWB;                             // [NWB][3][BN][64 B]
+  unsigned char* const ldsA = reinterpret_cast<unsigned char*>(smem);            // [NP][win][64 B]
+  unsigned char* const ldsW = ldsA + NP * win * ROWB;                            // [NWB][NP][BN][64 B]
 
   // Rows outside the matrix or masked out read as zero.  Instead of predicating every load of the loop (exec-mask
   // branches, ~16 scalar instructions per step), such a row's pointer is aimed once at a page of zeros and its per-step
@@ -152,20 +157,34 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = x[e] > 0.f ? x[e] : x[e] * p.pro_slope;
           }
-          u32x4 h, m, l;
-          split3x8(x, h, m, l);
           unsigned char* dst = ldsA + r * ROWB + ((((AQ ? kpart : 2 * kpart + g)) ^ swz(r)) << 4);
-          *reinterpret_cast<u32x4*>(dst) = h;
-          *reinterpret_cast<u32x4*>(dst + win * ROWB) = m;
-          *reinterpret_cast<u32x4*>(dst + 2 * win * ROWB) = l;
+          if constexpr (NP == 2) {
+            u32x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const Split2 t = split2h_pair(x[2 * e] * p.a_scale, x[2 * e + 1] * p.a_scale);
+              h[e] = t.h;
+              l[e] = t.l;
+            }
+            *reinterpret_cast<u32x4*>(dst) = h;
+            *reinterpret_cast<u32x4*>(dst + win * ROWB) = l;
+          } else {
+            u32x4 h, m, l;
+            split3x8(x, h, m, l);
+            *reinterpret_cast<u32x4*>(dst) = h;
+            *reinterpret_cast<u32x4*>(dst + win * ROWB) = m;
+            *reinterpret_cast<u32x4*>(dst + 2 * win * ROWB) = l;
+          }
         }
       }
     }
   };
-  // 3 * BN / 16 one-KiB pieces (16 weight rows x 64 B of one plane) per step, dealt round-robin to the four waves.
+  // NP * BN / 16 one-KiB pieces (16 weight rows x 64 B of one plane) per step, dealt round-robin to the four waves.
   // Lane L of a piece lands in LDS row L >> 2, slot L & 3, and therefore fetches k-slot (L & 3) ^ swizzle(row).
   auto dma_W = [&](int kb, int buf) {      // kb: first k column of the step (tap * Cin + chunk * 32)
-    constexpr int PIECES = 3 * BN / 16;
+    constexpr int PIECES = NP * BN / 16;
+    const unsigned short* const planes = NP == 2 ? p.W2 : p.W3;
+    const long pstride = NP == 2 ? p.w2_plane : p.w3_plane;
 #pragma unroll
     for (int i = 0; i < PIECES / 4; ++i) {
       const int pc = wave + 4 * i;
@@ -173,8 +192,8 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
       const int row = g16 * 16 + (lane >> 2);
       const int kslot = (lane & 3) ^ swz(row);
       const int n = min(n0 + row, p.n_rows_w - 1);      // rows past the weight matrix feed columns that are never stored
-      const unsigned short* src = p.W3 + (long)plane * p.w3_plane + (long)n * p.ldw + kb + 8 * kslot;
-      unsigned char* dst = ldsW + ((buf * 3 + plane) * BN + g16 * 16) * ROWB;      // wave-uniform; the DMA adds lane * 16
+      const unsigned short* src = planes + (long)plane * pstride + (long)n * p.ldw + kb + 8 * kslot;
+      unsigned char* dst = ldsW + ((buf * NP + plane) * BN + g16 * 16) * ROWB;      // wave-uniform; the DMA adds lane * 16
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
@@ -211,35 +230,47 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
       if constexpr (NWB == 2) dma_W(j2 * p.Cin + c2 * 32, (s + 1) & 1);
     }
     const unsigned char* la = ldsA + (wm * WM + r32 + j * dil) * ROWB;
-    const unsigned char* lw = ldsW + (NWB == 2 ? (s & 1) * 3 * BN * ROWB : 0) + (wn * WN + r32) * ROWB;
+    const unsigned char* lw = ldsW + (NWB == 2 ? (s & 1) * NP * BN * ROWB : 0) + (wn * WN + r32) * ROWB;
     // WM, WN and the 32-row fragment steps are multiples of 16 rows, so only r32 (and the tap's row offset) enter the keys
     const int swzw = swz(r32), swza = swz(r32 + j * dil);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {            // two k-steps of 16 per 32-channel chunk
-      bf16x8 a[MT][3], b[NT][3];
+      u32x4 a[MT][NP], b[NT][NP];
       const int koffa = ((2 * ks + half) ^ swza) << 4, koffw = ((2 * ks + half) ^ swzw) << 4;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          a[mt][pl] = *reinterpret_cast<const bf16x8*>(la + (pl * win + mt * 32) * ROWB + koffa);
+        for (int pl = 0; pl < NP; ++pl)
+          a[mt][pl] = *reinterpret_cast<const u32x4*>(la + (pl * win + mt * 32) * ROWB + koffa);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          b[nt][pl] = *reinterpret_cast<const bf16x8*>(lw + (pl * BN + nt * 32) * ROWB + koffw);
+        for (int pl = 0; pl < NP; ++pl)
+          b[nt][pl] = *reinterpret_cast<const u32x4*>(lw + (pl * BN + nt * 32) * ROWB + koffw);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           f32x16 t = acc[mt][nt];
           if (JV_ABLATE(p, 8)) continue;
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][2], b[nt][0], t, 0, 0, 0);   // smallest terms first
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][0], b[nt][2], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][1], b[nt][1], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][1], b[nt][0], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][0], b[nt][1], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][0], b[nt][0], t, 0, 0, 0);
+          if constexpr (NP == 2) {
+            auto mm = [&](const u32x4& x, const u32x4& y) {
+              t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), t, 0, 0, 0);
+            };
+            mm(a[mt][1], b[nt][0]);      // smallest terms first
+            mm(a[mt][0], b[nt][1]);
+            mm(a[mt][0], b[nt][0]);
+          } else {
+            auto mm = [&](const u32x4& x, const u32x4& y) {
+              t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), t, 0, 0, 0);
+            };
+            mm(a[mt][2], b[nt][0]);      // smallest terms first
+            mm(a[mt][0], b[nt][2]);
+            mm(a[mt][1], b[nt][1]);
+            mm(a[mt][1], b[nt][0]);
+            mm(a[mt][0], b[nt][1]);
+            mm(a[mt][0], b[nt][0]);
+          }
           acc[mt][nt] = t;
         }
     }
@@ -247,7 +278,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
     c = c2;
   }
   __syncthreads();
-  conv_epilogue<WM, WN, EPI>(p, out, acc, smem, m0, n0, wm, wn, t_start, t_loop);
+  conv_epilogue<WM, WN, EPI, NP == 2>(p, out, acc, smem, m0, n0, wm, wn, t_start, t_loop);
 }
 
 namespace {
@@ -255,16 +286,16 @@ namespace {
 template <int BM, int BN>
 size_t x6_lds_bytes(const ConvGemmArgs& a, int nwb = 1) {
   const int win = BM + (a.ntaps - 1) * a.tap_dil;
-  return (size_t)3 * (win + nwb * BN) * ROWB;
+  return (size_t)(a.W2 ? 2 : 3) * (win + nwb * BN) * ROWB;
 }
 
-template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int NWB>
-int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int NWB, int NP>
+int x6_launch4(const ConvGemmArgs& a, hipStream_t st) {
   static bool raised[64] = {};      // per device: the attribute belongs to the kernel's image on the current device
   int dev = 0;
   JV_HIP(hipGetDevice(&dev));
   if (!raised[dev & 63]) {
-    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, NWB>),
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, NWB, NP>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     raised[dev & 63] = true;
   }
@@ -284,7 +315,7 @@ int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, st);
-    hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, NWB>), dim3(nwg), dim3(256), lds, st, b, tiles_n);
+    hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, NWB, NP>), dim3(nwg), dim3(256), lds, st, b, tiles_n);
     (void)hipEventRecord(e1, st);
     (void)hipStreamSynchronize(st);
     float ms = 0.f;
@@ -307,9 +338,9 @@ int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
     }
     return JV_OK;
   }
-  hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, NWB>), dim3(tiles_m * tiles_n), dim3(256), lds, st, a, tiles_n);
+  hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, NWB, NP>), dim3(tiles_m * tiles_n), dim3(256), lds, st, a, tiles_n);
   if (prof) {
-    static const std::string name = std::string("conv_gemm_x6<") + std::to_string(BM) + "x" + std::to_string(BN) +
+    static const std::string name = std::string(NP == 2 ? "conv_gemm_h3<" : "conv_gemm_x6<") + std::to_string(BM) + "x" + std::to_string(BN) +
                                     (PRO == PRO_SNAKE ? ",snake" : PRO == PRO_LRELU ? ",lrelu" : "") +
                                     (EPI == 1 ? ",gelu" : EPI == 2 ? ",res" : EPI == 4 ? ",generic" : "") + ">";
     const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M);
@@ -319,6 +350,14 @@ int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
   }
   JV_HIP(hipGetLastError());
   return JV_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int NWB>
+int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
+  if constexpr (PRO == PRO_NONE) {
+    if (a.W2) return x6_launch4<BM, BN, WM, WN, PRO, EPI, NA2, NWB, 2>(a, st);
+  }
+  return x6_launch4<BM, BN, WM, WN, PRO, EPI, NA2, NWB, 3>(a, st);
 }
 
 // Weight planes always travel by LDS-DMA: two W buffers when both fit beside the A window in half a CU's LDS (the DMA of
@@ -335,7 +374,8 @@ int x6_launch2(const ConvGemmArgs& a, hipStream_t st) {
   } else {
     // Few tiles (small batches): occupancy cannot hide the weight DMA's latency, LDS is plentiful -> two W buffers
     const long tiles = (long)cdiv(a.M, BM) * cdiv(a.N, BN);
-    const bool two = tiles <= 1024 && x6_lds_bytes<BM, BN>(a, 2) <= 64 * 1024;
+    const bool two = (tiles <= 1024 && x6_lds_bytes<BM, BN>(a, 2) <= 64 * 1024) ||
+                     (a.W2 && 5 * x6_lds_bytes<BM, BN>(a, 2) <= 160 * 1024 && !dyn_env("JV_H3_NWB1"));   // still five per CU
     if (win <= 64) return two ? x6_launch3<BM, BN, WM, WN, PRO, EPI, 0, 2>(a, st) : x6_launch3<BM, BN, WM, WN, PRO, EPI, 0, 1>(a, st);
     return two ? x6_launch3<BM, BN, WM, WN, PRO, EPI, 1, 2>(a, st) : x6_launch3<BM, BN, WM, WN, PRO, EPI, 1, 1>(a, st);
   }
@@ -363,8 +403,14 @@ int x6_launch(const ConvGemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// Same contract as conv_gemm() (argument checks done there); requires a.W3.
-int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st) {
+// Same contract as conv_gemm() (argument checks done there); requires a.W3, or a.W2 + a.colscale (fp16x3, plain prologue).
+int conv_gemm_x6(const ConvGemmArgs& a0, hipStream_t st) {
+  ConvGemmArgs a = a0;
+  if (a.W2 && (a.pro != PRO_NONE || !a.colscale || !(a.a_scale > 0.f))) {
+    if (!a.W3) return fail(JV_ERR_ARG, "conv_gemm_x6: fp16x3 needs a plain prologue, colscale and a_scale");
+    a.W2 = nullptr;
+  }
+  if (!a.W2 && !a.W3) return fail(JV_ERR_ARG, "conv_gemm_x6: no weight planes");
   const int span = (a.ntaps - 1) * a.tap_dil;
   struct Cand { int bm, bn; double eff; size_t lds; int max_win; };
   // measured on the estimator shapes (tools/gemm_bench.py): the big tile amortises staging and barriers best.  The

@@ -94,6 +94,11 @@ void flow_graphs_drop(Context& c) {
   c.flow->graphs.clear();
 }
 
+// new weights: rows of the attention buffer written under the old ones may exceed the new V bound (registry.hip)
+void flow_ws_forget_attention(Context& c, hipStream_t st) {
+  if (c.flow && c.flow->att) (void)hipMemsetAsync(c.flow->att, 0, (size_t)c.flow->rows_alloc * 512 * sizeof(float), st);
+}
+
 namespace {
 
 // (t, dt) of the step the device-side counter points at, then advance it: the only step-dependent state of a solve
@@ -169,9 +174,15 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     return conv_gemm(a, 1, st);
   };
   // BasicTransformerBlock (transformer.py:355-443): h -> h, last GEMM may retarget its output
+  // the four linears of a block run fp16x3 when registry.hip proved their input range (GemmW::a_scale)
+  auto h3 = [&](ConvGemmArgs& a, const GemmW& m) {
+    if (c.exact_range || !m.w2 || !(m.a_scale > 0.f)) return;
+    a.W2 = m.w2; a.w2_plane = (long)m.n_rows * m.ldw; a.colscale = m.colscale; a.a_scale = m.a_scale;
+  };
   auto btb = [&](const BtbW& b, float* h, float* out, int ldo) -> int {
     JV_TRY(layernorm_rows(h, nullptr, w.ln, b.n1.g, b.n1.b, 1e-5f, g.M, 256, nullptr, st));
     ConvGemmArgs a = base_args(g, w.ln, 256, b.qkv, w.qkv, 1536);
+    h3(a, b.qkv);
     JV_TRY(conv_gemm(a, 1, st));
     AttnArgs at{};
     at.qkv = w.qkv; at.ld = 1536; at.k_off = 512; at.v_off = 1024; at.out = w.att; at.ldo = 512;
@@ -180,13 +191,16 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     JV_TRY(attention64(at, st));
     a = base_args(g, w.att, 512, b.out, h, 256);
     a.res1 = h; a.ldr1 = 256;
+    h3(a, b.out);
     JV_TRY(conv_gemm(a, 1, st));
     JV_TRY(layernorm_rows(h, nullptr, w.ln, b.n3.g, b.n3.b, 1e-5f, g.M, 256, nullptr, st));
     a = base_args(g, w.ln, 256, b.ff1, w.ff, 1024);
     a.act = ACT_GELU;
+    h3(a, b.ff1);
     JV_TRY(conv_gemm(a, 1, st));
     a = base_args(g, w.ff, 1024, b.ff2, out, ldo);
     a.res1 = h; a.ldr1 = 256;
+    h3(a, b.ff2);
     return conv_gemm(a, 1, st);
   };
 

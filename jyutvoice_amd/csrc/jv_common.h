@@ -84,6 +84,13 @@ struct ConvGemmArgs {
   const float* W;
   const unsigned short* W3;   // optional: the same matrix as three bf16 planes [3][n_rows_w][ldw] (bf16x6 path)
   long w3_plane;              // elements between planes
+  // optional fp16x3 path (conv_gemm_x6.hip, NP = 2): W2 = two fp16 planes of W[n][:] * 2^e_n, colscale[n] = 2^-e_n, and a
+  // power of two a_scale with |A| * a_scale < 65504 PROVEN by the caller (a load-time bound, registry.hip); the kernel
+  // returns acc * colscale[n] / a_scale.  Ignored unless W2 is set; plain prologue only.
+  const unsigned short* W2;
+  long w2_plane;
+  const float* colscale;
+  float a_scale;
   int ldw;
   int n_rows_w;    // rows of W that may be read (>= N, zero padded)
   int N;           // valid output columns

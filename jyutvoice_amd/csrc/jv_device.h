@@ -68,4 +68,19 @@ __device__ __forceinline__ Split3 split3_pair(const float x0, const float x1) {
   return {h, m, l};
 }
 
+// fp16x2 split of two fp32 values: x ~= h + l with h = fp16(x), l = fp16(x - h): 22 significant bits while l is a normal
+// fp16 (|x| >= 2^-3), an absolute error of at most 2^-25 below that (fp16 subnormals are kept by the conversion and by
+// v_mfma_f32_32x32x16_f16 on gfx950 -- tools/probes/f16_denorm.hip).  |x| must stay below 65504: callers scale by a power
+// of two chosen from a proven bound.
+typedef _Float16 jv_f16x2 __attribute__((ext_vector_type(2)));
+struct Split2 { unsigned h, l; };
+__device__ __forceinline__ Split2 split2h_pair(const float x0, const float x1) {
+  const jv_f32x2 x = {x0, x1};
+  const jv_f16x2 h = __builtin_convertvector(x, jv_f16x2);
+  const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];
+  const jv_f32x2 r = {r0, r1};
+  const jv_f16x2 l = __builtin_convertvector(r, jv_f16x2);
+  return {__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, l)};
+}
+
 }  // namespace jv

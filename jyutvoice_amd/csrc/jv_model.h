@@ -48,6 +48,10 @@ struct GemmW {
   const unsigned short* w3 = nullptr;   // three bf16 planes of w (split at load time), plane stride n_rows*ldw
   int ldw = 0, n_rows = 0, N = 0, Cin = 0, ntaps = 1;
   const float* bias = nullptr;
+  // fp16x3 path, attached only where a load-time bound on the layer's input exists (registry.hip `half3`):
+  const unsigned short* w2 = nullptr;   // two fp16 planes of w[n][:] * 2^e_n
+  const float* colscale = nullptr;      // 2^-e_n
+  float a_scale = 0.f;                  // power of two with bound(|input|) * a_scale < 65504; 0 = no bound, use bf16x6
 };
 
 struct LnW { const float* g = nullptr; const float* b = nullptr; };
@@ -113,6 +117,7 @@ struct Context {
   PromptW prompt;
   float* noise = nullptr;        // [80][15000] fixed CFM noise (device), supplied by the host
   bool noise_loaded = false;
+  bool exact_range = false;      // true: bf16x6 everywhere (jv_flow_set_contraction); false: fp16x3 where the range is proven
   bool step_graphs = false;      // replay the Euler step as a captured hipGraph (jv_flow_set_graph; never under the profiler)
   int attn_chunk = 0;            // > 0: streaming (chunk-causal) estimator attention, in frames (jv_flow_set_streaming)
   // workspace

@@ -250,6 +250,45 @@ __global__ void split3_kernel(const float* __restrict__ src, unsigned short* __r
   dst[2 * n + i] = __builtin_bit_cast(unsigned short, l);
 }
 
+// per row n of W [rows][ld]: amax[n] = max |w|, l1[n] = sum |w| over the first K columns (one wave per row)
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ w, int rows, int ld, int K,
+                                                        float* __restrict__ amax, float* __restrict__ l1) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= rows) return;
+  float m = 0.f, s = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float a = fabsf(w[(long)n * ld + k]);
+    m = fmaxf(m, a);      // NaN-free weights assumed; a NaN sum below disables the layer's fp16 path on the host
+    s += a;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, o));
+    s += __shfl_xor(s, o);
+  }
+  if (lane == 0) { amax[n] = m; l1[n] = s; }
+}
+
+// fp32 -> two fp16 planes of w * 2^e_n with max_k |w[n][k]| * 2^e_n in [2^13, 2^14); colscale[n] = 2^-e_n
+__global__ void split2h_kernel(const float* __restrict__ src, const float* __restrict__ amax, unsigned short* __restrict__ dst,
+                               float* __restrict__ colscale, long total, int ld) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int n = (int)(i / ld);
+  int ex = 0;
+  const float am = amax[n];
+  float sc = 1.f;
+  if (am > 0.f && am < INFINITY) {
+    (void)frexpf(am, &ex);                       // am = f * 2^ex, f in [0.5, 1)
+    sc = ldexpf(1.f, min(max(14 - ex, -60), 60));
+  }
+  const float x = src[i] * sc;
+  const _Float16 h = (_Float16)x;
+  const _Float16 l = (_Float16)(x - (float)h);
+  dst[i] = __builtin_bit_cast(unsigned short, h);
+  dst[total + i] = __builtin_bit_cast(unsigned short, l);
+  if (i == (long)n * ld) colscale[n] = 1.0f / sc;
+}
+
 // w[r][:] = v[r][:] * (g[r] / ||v[r][:]||)
 __global__ __launch_bounds__(256) void fold_wn_kernel(const float* __restrict__ v, const float* __restrict__ g,
                                                       float* __restrict__ w, int cols) {
@@ -267,6 +306,27 @@ __global__ __launch_bounds__(256) void fold_wn_kernel(const float* __restrict__ 
 }
 
 }  // namespace
+
+// test hook: fp16x3 planes + column scales of an arbitrary [rows][ld] matrix (jv_op_linear_h3); stats = 2 * rows floats
+int split2h_planes(const float* src, int rows, int ld, float* stats, unsigned short* dst, float* colscale, hipStream_t st) {
+  hipLaunchKernelGGL(row_stats_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, src, rows, ld, ld, stats, stats + rows);
+  const long total = (long)rows * ld;
+  hipLaunchKernelGGL(split2h_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, src, stats, dst, colscale, total, ld);
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+// largest power of two s with bound * s <= 60000 (fp16 max 65504 less a margin for the fp32 roundings on the way), 0 if
+// the bound is unusable
+float h3_scale_for_bound(float bound) {
+  if (!(bound > 0.f) || !(bound < 1e30f)) return 0.f;
+  int e = (int)floorf(log2f(60000.f / bound));
+  if (e < -24) return 0.f;
+  if (e > 24) e = 24;
+  float s = ldexpf(1.f, e);
+  while (bound * s > 60000.f) s *= 0.5f;
+  return s;
+}
 
 // test hook: split an arbitrary [n] fp32 matrix into bf16x6 planes (used by jv_op_conv_gemm)
 int split3_planes(const float* src, unsigned short* dst, long n, hipStream_t st) {
@@ -317,6 +377,40 @@ struct Packer {
     if (!d) return;
     hipLaunchKernelGGL(split3_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, g.w, reinterpret_cast<unsigned short*>(d), n);
     g.w3 = reinterpret_cast<const unsigned short*>(d);
+  }
+  // max |x| of a small device vector (load time only: synchronous)
+  float host_maxabs(const float* dev, int n, int stride = 1) {
+    if (!dev || rc != JV_OK) return NAN;
+    std::vector<float> h((size_t)n * stride);
+    if (hipMemcpyAsync(h.data(), dev, h.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+      rc = fail(JV_ERR_HIP, "bound readback failed");
+      return NAN;
+    }
+    float m = 0.f;
+    for (int i = 0; i < n; ++i) {
+      const float a = fabsf(h[(size_t)i * stride]);
+      if (a != a) return NAN;
+      m = fmaxf(m, a);
+    }
+    return m;
+  }
+  // attach the fp16x3 planes; returns max over rows [r0, r1) of sum_k |w| (for the bound of what this layer produces)
+  float half3(GemmW& g, int r0 = 0, int r1 = -1) {
+    if (!g.w || rc != JV_OK || g.ntaps != 1) return NAN;
+    const long n = (long)g.n_rows * g.ldw;
+    float* d = alloc((size_t)n + 8);             // 2 planes x 2 bytes
+    float* cs = alloc((size_t)g.n_rows);
+    float* stats = alloc((size_t)2 * g.n_rows);
+    if (!d || !cs || !stats) return NAN;
+    if (split2h_planes(g.w, g.n_rows, g.ldw, stats, reinterpret_cast<unsigned short*>(d), cs, st) != JV_OK) {
+      rc = JV_ERR_HIP;
+      return NAN;
+    }
+    g.w2 = reinterpret_cast<const unsigned short*>(d);
+    g.colscale = cs;
+    if (r1 < 0) r1 = g.n_rows;
+    return host_maxabs(stats + g.n_rows + r0, r1 - r0);
   }
   // conv weight [cout][cin][k] (device, plain) -> GemmW with cin padded to cinp
   GemmW conv(const float* w, int cout, int cin, int k, int cinp, const float* bias) {
@@ -392,6 +486,7 @@ struct Packer {
 }  // namespace
 
 int scale_copy(const float* x, float* y, float s, int n, hipStream_t st);   // promptops.hip
+void flow_ws_forget_attention(Context& c, hipStream_t st);                  // flow.hip
 
 int finalize_model(Context& c, int model, hipStream_t st) {
   for (const RawTensor& t : c.raw)
@@ -458,6 +553,7 @@ int finalize_model(Context& c, int model, hipStream_t st) {
     for (int i = 0; i < EST_NMID; ++i) stage[1 + i] = p + "mid_blocks." + S(i) + ".";
     stage[EST_NRES - 1] = p + "up_blocks.0.";
     std::vector<std::string> tw, tb;
+    float v_bound = 0.f;
     for (int i = 0; i < EST_NRES; ++i) {
       const std::string q = stage[i] + "0.";
       const int cin = i == 0 ? EST_IN : (i == EST_NRES - 1 ? 2 * EST_CH : EST_CH);
@@ -477,8 +573,27 @@ int finalize_model(Context& c, int model, hipStream_t st) {
         w.n3 = pk.ln(b + "norm3.", "weight", "bias");
         w.ff1 = pk.linear(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", EST_FF, EST_CH);
         w.ff2 = pk.linear(b + "ff.net.2.weight", b + "ff.net.2.bias", EST_CH, EST_FF);
+        // fp16x3 where the input range is proven at load time (conv_gemm_x6.hip, NP = 2).  |LayerNorm_256(x) g + b| <=
+        // sqrt(255) max|g| + max|b|; a Linear of a bounded input is bounded by its largest row L1 norm; attention
+        // returns convex combinations of its V rows; |gelu(x)| <= |x|.
+        const float b1 = 16.f * pk.host_maxabs(w.n1.g, EST_CH) + pk.host_maxabs(w.n1.b, EST_CH);
+        const float b3 = 16.f * pk.host_maxabs(w.n3.g, EST_CH) + pk.host_maxabs(w.n3.b, EST_CH);
+        const float l1_v = pk.half3(w.qkv, 2 * EST_INNER, 3 * EST_INNER);
+        (void)pk.half3(w.out);
+        const float l1_ff1 = pk.half3(w.ff1);
+        (void)pk.half3(w.ff2);
+        w.qkv.a_scale = h3_scale_for_bound(b1);
+        w.ff1.a_scale = h3_scale_for_bound(b3);
+        w.ff2.a_scale = h3_scale_for_bound(l1_ff1 * b3 + pk.host_maxabs(w.ff1.bias, EST_FF));
+        v_bound = fmaxf(v_bound, l1_v * b1);
+        if (!(l1_v * b1 < 1e30f)) v_bound = INFINITY;
       }
     }
+    // the attention buffer is shared by all 56 blocks (and keeps rows of earlier calls between the utterances' windows):
+    // one scale from the largest V bound
+    for (int i = 0; i < EST_NRES; ++i)
+      for (int j = 0; j < EST_NBLK; ++j) e.blk[i][j].out.a_scale = h3_scale_for_bound(v_bound);
+    flow_ws_forget_attention(c, st);
     e.temb_all = pk.concat(tw, tb, EST_CH, EST_TIME);
     e.down_conv = pk.conv_named(p + "down_blocks.0.2.", EST_CH, EST_CH, 3);
     e.up_conv = pk.conv_named(p + "up_blocks.0.2.", EST_CH, EST_CH, 3);

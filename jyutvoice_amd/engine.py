@@ -107,6 +107,11 @@ class Engine:
         """replay the Euler step of cfm_solve as a captured hipGraph (default off: measured no faster; same results)"""
         check(self.lib.jv_flow_set_graph(self._h, 1 if on else 0))
 
+    def set_exact_range(self, on: bool = True):
+        """True: bf16x6 for every contraction; False (default): fp16x3 on the estimator linears whose input range is proven
+        at load time (jv_flow_set_contraction)"""
+        check(self.lib.jv_flow_set_contraction(self._h, 1 if on else 0))
+
     def flow_estimator(self, x, mask_lens, mu, t, spks, cond):
         """[B2,80,T] tensors on the device; mask_lens int32 [B2] or None."""
         B2, _, T = x.shape
@@ -222,6 +227,18 @@ def op_conv_gemm(A, W, bias=None, ntaps=1, tap_row0=0, dil=1, M=None, act="none"
     check(lib.jv_op_conv_gemm(_ptr(A), rows, M, cin, ntaps, tap_row0, dil, _ptr(W), N, _ptr(bias), _lib.ACT[act],
                               _lib.PRO[prologue], _ptr(alpha), float(slope), _ptr(g), _ptr(b), float(ln_eps), _ptr(rowmask),
                               _ptr(res), _ptr(out), _stream(A.device)))
+    return out
+
+
+def op_linear_h3(A, W, bias=None, act="none", res=None, a_bound=None):
+    """fp16x3 main loop (jv_flow_set_contraction): A [rows, K], W [N, K]; a_bound >= max |A| (default: measured)."""
+    lib = _lib.load()
+    rows, K = A.shape
+    N = W.shape[0]
+    out = torch.empty(rows, N, device=A.device)
+    bound = float(A.abs().max()) if a_bound is None else float(a_bound)
+    check(lib.jv_op_linear_h3(_ptr(A), rows, rows, K, _ptr(W), N, _ptr(bias), _lib.ACT[act], _ptr(res), bound, _ptr(out),
+                              _stream(A.device)))
     return out
 
 

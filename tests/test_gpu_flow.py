@@ -151,3 +151,26 @@ def test_step_graph_equals_eager(eng):
     finally:
         eng.set_streaming(0)
         eng.set_step_graph(False)
+
+
+def test_contraction_modes_agree(eng):
+    """jv_flow_set_contraction: the default (fp16x3 on the linears whose input range the library proved at load time) and
+    exact_range (bf16x6 everywhere) both meet the fixtures, and differ from each other by fp32 rounding noise only"""
+    g3 = load_golden("G3_estimator")
+    g4 = load_golden("G4_cfm")
+    lens = g3["mask"].sum(dim=(1, 2)).to(torch.int32)
+    T = g4["mu"].shape[2]
+    outs = {}
+    try:
+        for exact in (True, False):
+            eng.set_exact_range(exact)
+            est = eng.flow_estimator(g3["x"], lens, g3["mu"], g3["t"], g3["spks"], g3["cond"])
+            mel = eng.cfm_solve(g4["mu"], None, g4["spks"], torch.zeros(1, 80, T), 10, 1.0, t_span=g4["t_span_n10"])
+            assert md(est, g3["out"]) <= 1e-4, exact
+            assert md(mel, g4["mel_n10"]) <= 2e-4, exact
+            outs[exact] = (est, mel)
+    finally:
+        eng.set_exact_range(False)
+    assert md(outs[True][0], outs[False][0]) <= 2e-5
+    assert md(outs[True][1], outs[False][1]) <= 1e-4
+    assert not torch.equal(outs[True][0], outs[False][0])      # the switch really selects another kernel

@@ -245,3 +245,80 @@ def test_x6_weight_dma_race_screen(dev, x6, monkeypatch, tile, K):
     for i in range(40):
         noise.normal_()                                   # streaming writes in flight beside the GEMM
         assert torch.equal(op_conv_gemm(A, W, b), first), i
+
+
+# ---- fp16x3 main loop (jv_flow_set_contraction): two fp16 planes per operand after an exact power-of-two scaling chosen
+# from a proven bound on |A|; three MFMA products; the estimator's LayerNorm / attention / GELU fed linears use it -------
+
+@pytest.mark.parametrize("M,K,N", [(300, 256, 1536), (19, 1024, 256), (1000, 512, 80), (4100, 256, 256), (5000, 256, 1024)])
+def test_h3_linear_fp32_accuracy(dev, M, K, N):
+    """LayerNorm-like input (|x| <= 16 max|g| + max|b| is the bound the library proves): same bound against fp64 as the
+    fp32-MFMA and bf16x6 kernels"""
+    from jyutvoice_amd.engine import op_linear_h3
+    g = torch.Generator().manual_seed(M + K + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K) * torch.exp(torch.randn(N, 1, generator=g))   # rows of different scale
+    b = torch.randn(N, generator=g)
+    out = op_linear_h3(A.to(dev), W.to(dev), b.to(dev), a_bound=16 * 1.35 + 0.1)
+    want = A.double() @ W.double().T + b.double()
+    assert rel_err(out, want) < 2e-6
+    col_scale = W.double().abs().max(dim=1).values.clamp_min(1e-30) * math.sqrt(K) + b.double().abs()
+    assert float(((out.double().cpu() - want).abs() / col_scale).max()) < 2e-6
+
+
+@pytest.mark.parametrize("tile", ["0", "1", "2", "3", "4"])
+def test_h3_every_tile_variant(dev, monkeypatch, tile):
+    """each tile shape of the main loop with two planes, ragged M and N, plain / GELU / residual epilogues"""
+    from jyutvoice_amd.engine import op_linear_h3
+    monkeypatch.setenv("JV_TILE", tile)
+    g = torch.Generator().manual_seed(140 + int(tile))
+    M, K, N = 1000, 256, 392
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    want = A.double() @ W.double().T + b.double()
+    assert rel_err(op_linear_h3(A.to(dev), W.to(dev), b.to(dev)), want) < 2e-6
+    assert rel_err(op_linear_h3(A.to(dev), W.to(dev), b.to(dev), act="gelu"), F.gelu(want)) < 2e-6
+    assert rel_err(op_linear_h3(A.to(dev), W.to(dev), b.to(dev), res=res.to(dev)), want + res.double()) < 2e-6
+    assert rel_err(op_linear_h3(A.to(dev), W.to(dev), b.to(dev), act="silu"), F.silu(want)) < 2e-6      # generic epilogue
+
+
+def test_h3_range_contract(dev):
+    """values AT the proven bound stay finite and exact to the same tolerance (the scale leaves fp16's 65504 a margin);
+    values far below it degrade gracefully: absolute error <= 2^-25 / scale per element, i.e. ~1e-12 of the bound"""
+    from jyutvoice_amd.engine import op_linear_h3
+    g = torch.Generator().manual_seed(7)
+    M, K, N = 512, 256, 256
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bound = 700.0
+    A = (torch.rand(M, K, generator=g) * 2 - 1) * bound
+    A[0, :] = bound
+    A[1, :] = -bound
+    out = op_linear_h3(A.to(dev), W.to(dev), a_bound=bound)
+    want = A.double() @ W.double().T
+    assert torch.isfinite(out).all()
+    assert rel_err(out, want) < 2e-6
+    for shrink in (1e-2, 1e-4, 1e-6):          # whole tensor far below the bound the scale was chosen for
+        As = A * shrink
+        out = op_linear_h3(As.to(dev), W.to(dev), a_bound=bound)
+        want = As.double() @ W.double().T
+        err = float((out.double().cpu() - want).abs().max())
+        assert err < 2e-6 * float(want.abs().max()) + 1e-9 * bound * 1e-3, (shrink, err)
+
+
+def test_h3_weight_dma_race_screen(dev, monkeypatch):
+    """as test_x6_weight_dma_race_screen, for the two-plane layout with two weight buffers on the 64x64 tile"""
+    from jyutvoice_amd.engine import op_linear_h3
+    monkeypatch.setenv("JV_TILE", "2")
+    g = torch.Generator().manual_seed(99)
+    M, K, N = 3000, 1024, 384
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    first = op_linear_h3(A, W, b, a_bound=8.0)
+    assert rel_err(first, A.double().cpu() @ W.double().cpu().T + b.double().cpu()) < 2e-6
+    noise = torch.empty(64 << 20, device=dev)
+    for i in range(40):
+        noise.normal_()
+        assert torch.equal(op_linear_h3(A, W, b, a_bound=8.0), first), i
