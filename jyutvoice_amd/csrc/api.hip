@@ -277,6 +277,19 @@ int jv_op_attention(const float* qkv, const int32_t* lens, int B, int G, int S, 
   return jv::attention64(at, static_cast<hipStream_t>(stream));
 }
 
+// the fp16x3 attention kernel; q_bound, k_bound, v_bound: the caller's proven bounds on |q|, |k|, |v| (test hook)
+int jv_op_attention_h3(const float* qkv, const int32_t* lens, int B, int G, int S, int L, float q_bound, float k_bound,
+                       float v_bound, float* out, void* stream) {
+  jv::AttnArgs at{};
+  at.qkv = qkv; at.ld = 1536; at.k_off = 512; at.v_off = 1024; at.out = out; at.ldo = 512;
+  at.B = B; at.H = 8; at.G = G; at.S = S; at.L = L; at.lens = lens; at.chunk = 0;
+  at.q_scale = jv::h3_scale_for_bound(q_bound * 0.1803369f);
+  at.k_scale = jv::h3_scale_for_bound(k_bound);
+  at.v_scale = jv::h3_scale_for_bound(v_bound);
+  if (!(at.q_scale > 0.f && at.k_scale > 0.f && at.v_scale > 0.f)) return jv::fail(JV_ERR_ARG, "jv_op_attention_h3: unusable bound");
+  return jv::attention64(at, static_cast<hipStream_t>(stream));
+}
+
 int jv_op_layernorm(const float* x, const float* g, const float* b, float eps, int64_t rows, int C, float* out, void* stream) {
   return jv::layernorm_rows(x, nullptr, out, g, b, eps, rows, C, nullptr, static_cast<hipStream_t>(stream));
 }

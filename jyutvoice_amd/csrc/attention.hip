@@ -181,7 +181,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // bf16x6 kernel: unpadded tiles [3 planes][32 keys][128 B] and [3][64 d][64 B]; slot keys: a ds_read_b128 lane group
 // holds every key parity twice per value of (key >> 1) & 7, and every 64-byte quadrant once per value of (row >> 2) & 3
-constexpr int XK_TILE = 3 * 32 * 128, XV_TILE = 3 * 64 * 64;
+constexpr int XK_PLANE = 32 * 128, XV_PLANE = 64 * 64;
 __device__ __forceinline__ int xk_swz(int key) { return (key >> 1) & 7; }
 __device__ __forceinline__ int xv_swz(int row) { return (row >> 2) & 3; }
 
@@ -197,18 +197,50 @@ __device__ __forceinline__ float half_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-__device__ __forceinline__ f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// NP = 3: six bf16 products of (h, m, l) planes; NP = 2: three fp16 products of (h, l) planes (conv_gemm_x6.hip)
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_planes(const u32x4 (&a)[NP], const u32x4 (&b)[NP], f32x16 c) {
+  if constexpr (NP == 2) {
+    auto mm = [&](const u32x4& x, const u32x4& y) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+    };
+    mm(a[1], b[0]);
+    mm(a[0], b[1]);
+    mm(a[0], b[0]);
+  } else {
+    auto mm = [&](const u32x4& x, const u32x4& y) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
+    };
+    mm(a[2], b[0]);
+    mm(a[0], b[2]);
+    mm(a[1], b[1]);
+    mm(a[1], b[0]);
+    mm(a[0], b[1]);
+    mm(a[0], b[0]);
+  }
   return c;
 }
 
-template <int NW, int WPE>
+// one pair of fp32 values -> NP plane dwords (bf16 h, m, l or fp16 h, l)
+template <int NP>
+__device__ __forceinline__ void split_pair(const float x0, const float x1, unsigned (&o)[NP]) {
+  if constexpr (NP == 2) {
+    const Split2 t = split2h_pair(x0, x1);
+    o[0] = t.h; o[1] = t.l;
+  } else {
+    const Split3 t = split3_pair(x0, x1);
+    o[0] = t.h; o[1] = t.m; o[2] = t.l;
+  }
+}
+
+// NP = 2 (fp16x3): q, k, v are multiplied by the exact powers of two p.q_scale, p.k_scale, p.v_scale, which the caller
+// chose from PROVEN bounds so that nothing reaches fp16's 65504; the scores are scaled back inside the exp2 argument, the
+// probabilities are kept as p * 2^10 (<= 1024; the factor cancels in the normalisation), and v_scale leaves with 1 / l.
+template <int NW, int WPE, int NP>
 __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs p) {
+  constexpr int XK_TILE = NP * XK_PLANE, XV_TILE = NP * XV_PLANE;
   // Two buffers per operand, one barrier per key tile: tile kt + 1 is split and stored into the other buffer while tile kt
   // is being used.  Rows are unpadded (K: 128 B = 64 d, V^T: 64 B = 32 keys) with XOR-swizzled 16-byte slots, which keeps
   // the ds_read_b128 fragment fetches conflict-free and the two buffers within 48 KiB (three workgroups per CU).
@@ -237,7 +269,11 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
   const bool active = q0 < p.L;
 
   // Q planes: lane (query, half) holds d = 16 s + 8 half + j for k-step s, pre-scaled by log2(e)/8
-  bf16x8 q[4][3];
+  u32x4 q[4][NP];
+  const float qsc = 0.125f * 1.44269504088896340736f * (NP == 2 ? p.q_scale : 1.f);
+  const float ksc = NP == 2 ? p.k_scale : 1.f, vsc = NP == 2 ? p.v_scale : 1.f;
+  const float sinv = NP == 2 ? 1.0f / (p.q_scale * p.k_scale) : 1.f;      // powers of two: exact
+  constexpr float pshift = NP == 2 ? 10.f : 0.f;
   {
     const int qi = q0 + r32;
     const float* src = p.qkv + (rowbase + qi) * p.ld + h * 64 + 8 * half;
@@ -248,16 +284,14 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
         t0 = *reinterpret_cast<const f32x4*>(src + 16 * s);
         t1 = *reinterpret_cast<const f32x4*>(src + 16 * s + 4);
       }
-      u32x4 qh, qm, ql;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        constexpr float sc = 0.125f * 1.44269504088896340736f;
-        const float x0 = (e < 2 ? t0[2 * e] : t1[2 * e - 4]) * sc, x1 = (e < 2 ? t0[2 * e + 1] : t1[2 * e - 3]) * sc;
-        { const Split3 t_ = split3_pair(x0, x1); qh[e] = t_.h; qm[e] = t_.m; ql[e] = t_.l; }
+        const float x0 = (e < 2 ? t0[2 * e] : t1[2 * e - 4]) * qsc, x1 = (e < 2 ? t0[2 * e + 1] : t1[2 * e - 3]) * qsc;
+        unsigned o[NP];
+        split_pair<NP>(x0, x1, o);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) q[s][pl][e] = o[pl];
       }
-      q[s][0] = __builtin_bit_cast(bf16x8, qh);
-      q[s][1] = __builtin_bit_cast(bf16x8, qm);
-      q[s][2] = __builtin_bit_cast(bf16x8, ql);
     }
   }
 
@@ -309,13 +343,17 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
       const int idx = tid + i * NT;
       if ((512 % NT) != 0 && idx >= 512) continue;
       const int key = idx >> 4, c4 = idx & 15;
-      u32x2 hh, mm, ll;
-      { const Split3 t_ = split3_pair(pk[i][0], pk[i][1]); hh[0] = t_.h; mm[0] = t_.m; ll[0] = t_.l; }
-      { const Split3 t_ = split3_pair(pk[i][2], pk[i][3]); hh[1] = t_.h; mm[1] = t_.m; ll[1] = t_.l; }
+      unsigned o0_[NP], o1_[NP];
+      if constexpr (NP == 2) {
+        split_pair<NP>(pk[i][0] * ksc, pk[i][1] * ksc, o0_);
+        split_pair<NP>(pk[i][2] * ksc, pk[i][3] * ksc, o1_);
+      } else {
+        split_pair<NP>(pk[i][0], pk[i][1], o0_);
+        split_pair<NP>(pk[i][2], pk[i][3], o1_);
+      }
       unsigned char* dst = bK + key * 128 + ((((c4 >> 1) ^ xk_swz(key)) << 4) | ((c4 & 1) << 3));
-      *reinterpret_cast<u32x2*>(dst) = hh;
-      *reinterpret_cast<u32x2*>(dst + 32 * 128) = mm;
-      *reinterpret_cast<u32x2*>(dst + 64 * 128) = ll;
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * XK_PLANE) = u32x2{o0_[pl], o1_[pl]};
     }
 #pragma unroll
     for (int j = 0; j < NVG; ++j) {             // 4 consecutive keys stay consecutive under the bit swap
@@ -323,13 +361,17 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
       if ((8 % NW) != 0 && g >= 8) continue;
       const int key = 4 * g;
       const int pos = (key & 0x13) | ((key & 4) << 1) | ((key & 8) >> 1);       // bf16 index inside the 32-key row
-      u32x2 hh, mm, ll;
-      { const Split3 t_ = split3_pair(pv[j][0], pv[j][1]); hh[0] = t_.h; mm[0] = t_.m; ll[0] = t_.l; }
-      { const Split3 t_ = split3_pair(pv[j][2], pv[j][3]); hh[1] = t_.h; mm[1] = t_.m; ll[1] = t_.l; }
+      unsigned o0_[NP], o1_[NP];
+      if constexpr (NP == 2) {
+        split_pair<NP>(pv[j][0] * vsc, pv[j][1] * vsc, o0_);
+        split_pair<NP>(pv[j][2] * vsc, pv[j][3] * vsc, o1_);
+      } else {
+        split_pair<NP>(pv[j][0], pv[j][1], o0_);
+        split_pair<NP>(pv[j][2], pv[j][3], o1_);
+      }
       unsigned char* dst = bV + vd * 64 + ((((pos >> 3) ^ xv_swz(vd)) << 4) | (((pos >> 2) & 1) << 3));
-      *reinterpret_cast<u32x2*>(dst) = hh;
-      *reinterpret_cast<u32x2*>(dst + 64 * 64) = mm;
-      *reinterpret_cast<u32x2*>(dst + 128 * 64) = ll;
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * XV_PLANE) = u32x2{o0_[pl], o1_[pl]};
     }
   };
   if (nkt > 0) {
@@ -355,12 +397,12 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
     const unsigned char* kr = ldsK + r32 * 128;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      bf16x8 a[3];
+      u32x4 a[NP];
       const int ko = ((2 * st + half) ^ xk_swz(r32)) << 4;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(kr + pl * 32 * 128 + ko);
-      if (!JV_ABLATE(p, 16)) s = mfma6(a, q[st], s);
-      else s[st] += (float)a[0][0] + (float)a[1][1] + (float)a[2][2];
+      for (int pl = 0; pl < NP; ++pl) a[pl] = *reinterpret_cast<const u32x4*>(kr + pl * XK_PLANE + ko);
+      if (!JV_ABLATE(p, 16)) s = mfma_planes<NP>(a, q[st], s);
+      else s[st] += __uint_as_float(a[0][0] ^ a[1][1]);
     }
     if (!JV_ABLATE(p, 32)) {
     if (__builtin_amdgcn_ballot_w64(k0 + 32 > kend) != 0) {     // wave-uniform: only tiles that straddle a mask edge
@@ -373,7 +415,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
     float mt = s[0];
 #pragma unroll
     for (int e = 1; e < 16; ++e) mt = fmaxf(mt, s[e]);
-    mt = half_max(mt);
+    mt = half_max(mt) * sinv;
     const float m_new = fmaxf(m_run, mt);
     // v_exp_f32 directly: exp2f() wraps it in denormal-range scaling (6 more VALU ops per score); weights below 2^-126
     // flush to zero instead, far under the fp32 rounding of the row sum
@@ -381,7 +423,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
     float lt = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      s[e] = __builtin_amdgcn_exp2f(s[e] - m_new);
+      s[e] = __builtin_amdgcn_exp2f(NP == 2 ? fmaf(s[e], sinv, pshift - m_new) : s[e] - m_new);
       lt += s[e];
     }
     lt = half_sum(lt);
@@ -396,20 +438,24 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
     const unsigned char* vr = ldsV + r32 * 64;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-      u32x4 ph, pm, pl_;
+      u32x4 pb[NP];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const Split3 t_ = split3_pair(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]); ph[e] = t_.h; pm[e] = t_.m; pl_[e] = t_.l; }
-      const bf16x8 pb[3] = {__builtin_bit_cast(bf16x8, ph), __builtin_bit_cast(bf16x8, pm), __builtin_bit_cast(bf16x8, pl_)};
-      bf16x8 a[3];
+      for (int e = 0; e < 4; ++e) {
+        unsigned o[NP];
+        split_pair<NP>(s[8 * st + 2 * e], s[8 * st + 2 * e + 1], o);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) pb[pl][e] = o[pl];
+      }
+      u32x4 a[NP];
       const int vo = ((2 * st + half) ^ xv_swz(r32)) << 4;       // rows r32 and r32 + 32 share the key
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(vr + pl * 64 * 64 + vo);
-      if (!JV_ABLATE(p, 8)) o0 = mfma6(a, pb, o0);
-      else o0[st] += (float)a[0][0] + (float)a[1][1] + (float)a[2][2] + (float)pb[0][0] + (float)pb[1][1] + (float)pb[2][2];
+      for (int pl = 0; pl < NP; ++pl) a[pl] = *reinterpret_cast<const u32x4*>(vr + pl * XV_PLANE + vo);
+      if (!JV_ABLATE(p, 8)) o0 = mfma_planes<NP>(a, pb, o0);
+      else o0[st] += __uint_as_float(a[0][0] ^ a[1][1] ^ pb[0][0] ^ pb[1][1]);
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(vr + (pl * 64 + 32) * 64 + vo);
-      if (!JV_ABLATE(p, 8)) o1 = mfma6(a, pb, o1);
-      else o1[st] += (float)a[0][0] + (float)a[1][1] + (float)a[2][2];
+      for (int pl = 0; pl < NP; ++pl) a[pl] = *reinterpret_cast<const u32x4*>(vr + (pl * 64 + 32) * 64 + vo);
+      if (!JV_ABLATE(p, 8)) o1 = mfma_planes<NP>(a, pb, o1);
+      else o1[st] += __uint_as_float(a[0][0] ^ a[1][1]);
     }
     }
     // the one barrier of the tile: tile kt + 1 is complete in the other buffer, and nobody reads this one any more
@@ -418,7 +464,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
 
   const int qi = q0 + r32;
   if (active && qi < p.L) {
-    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    const float inv = l_run > 0.f ? (1.0f / vsc) / l_run : 0.f;
     float* dst = p.out + (rowbase + qi) * p.ldo + h * 64 + 4 * half;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -434,7 +480,9 @@ namespace {
 
 template <int NW>
 void launch_x6(const AttnArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL((attn64_x6_kernel<NW, (NW == 2 ? 2 : 3)>), dim3(cdiv(a.L, 32 * NW) * a.H * a.B), dim3(64 * NW), 0, st, a);
+  const dim3 grid(cdiv(a.L, 32 * NW) * a.H * a.B);
+  if (a.q_scale > 0.f) hipLaunchKernelGGL((attn64_x6_kernel<NW, (NW == 2 ? 2 : 3), 2>), grid, dim3(64 * NW), 0, st, a);
+  else hipLaunchKernelGGL((attn64_x6_kernel<NW, (NW == 2 ? 2 : 3), 3>), grid, dim3(64 * NW), 0, st, a);
 }
 
 }  // namespace
@@ -444,6 +492,7 @@ int attention64(const AttnArgs& a, hipStream_t st) {
   if ((a.ld & 3) || (a.ldo & 3) || (a.k_off & 3) || (a.v_off & 3))
     return fail(JV_ERR_ARG, "attention64: strides/offsets must be multiples of 4 floats");
   static const bool fp32_path = getenv("JV_ATTN_FP32") != nullptr;
+  if (a.q_scale > 0.f && !(a.k_scale > 0.f && a.v_scale > 0.f)) return fail(JV_ERR_ARG, "attention64: fp16x3 needs all three scales");
   if (const char* ab = tuning_env("JV_ABLATE")) const_cast<AttnArgs&>(a).ablate = atoi(ab);
   const bool prof = prof_on();
   if (prof) prof_begin(st);
@@ -468,7 +517,8 @@ int attention64(const AttnArgs& a, hipStream_t st) {
     }
     static const char* const names[9] = {"", "", "attn64_x6<2 waves>", "attn64_x6<3 waves>", "attn64_x6<4 waves>", "attn64_x6<5 waves>",
                                          "attn64_x6<6 waves>", "attn64_x6<7 waves>", "attn64_x6<8 waves>"};
-    name = names[nw];
+    static const char* const names_h3[9] = {"", "", "attn64_h3<2 waves>", "", "attn64_h3<4 waves>", "", "", "", "attn64_h3<8 waves>"};
+    name = a.q_scale > 0.f ? names_h3[nw] : names[nw];
   }
   if (prof) {
     // algorithmic (full-length) figure of SURVEY.md 8(d): QK^T + PV = 4*L*L*64 per head; q,k,v,o once

@@ -434,9 +434,10 @@ int conv_gemm_x6(const ConvGemmArgs& a0, hipStream_t st) {
       !dyn_env("JV_NO_T128x64"))
     best = 4;
   if (best == 0 && cands[3].bm + span <= cands[3].max_win && !dyn_env("JV_NO_T160")) {
-    // both run two workgroups per CU: rounds of 512 resident tiles x rows per tile
-    const long r128 = cdivl((long)cdiv(a.M, 128) * cdiv(a.N, 128), 512) * 128;
-    const long r160 = cdivl((long)cdiv(a.M, 160) * cdiv(a.N, 128), 512) * 160;
+    // both run two workgroups per CU (three with two planes): rounds of resident tiles x rows per tile
+    const long slots = a.W2 ? 768 : 512;
+    const long r128 = cdivl((long)cdiv(a.M, 128) * cdiv(a.N, 128), slots) * 128;
+    const long r160 = cdivl((long)cdiv(a.M, 160) * cdiv(a.N, 128), slots) * 160;
     if ((double)r160 / cands[3].eff < (double)r128) best = 3;
   }
   if (const char* force = dyn_env("JV_TILE")) {

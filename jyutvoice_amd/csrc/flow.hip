@@ -188,6 +188,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     at.qkv = w.qkv; at.ld = 1536; at.k_off = 512; at.v_off = 1024; at.out = w.att; at.ldo = 512;
     at.B = B2; at.H = EST_HEADS; at.G = FLOW_G; at.S = g.S; at.L = g.T; at.lens = w.lens2;
     at.chunk = c.attn_chunk;
+    if (!c.exact_range && b.q_scale > 0.f) { at.q_scale = b.q_scale; at.k_scale = b.k_scale; at.v_scale = b.v_scale; }
     JV_TRY(attention64(at, st));
     a = base_args(g, w.att, 512, b.out, h, 256);
     a.res1 = h; a.ldr1 = 256;

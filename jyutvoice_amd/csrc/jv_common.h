@@ -149,6 +149,9 @@ struct AttnArgs {
   int B, H;
   int G, S, L;        // row geometry: utterance b, frame t at row G + b*S + t, t < L
   const int* lens;    // [B] valid keys per utterance (device), or null = L
+  // fp16x3 contractions (attention.hip, NP = 2) when q_scale > 0: exact powers of two with |q| log2(e)/8 * q_scale,
+  // |k| * k_scale, |v| * v_scale < 65504 PROVEN by the caller; 0 = bf16x6, any fp32 operand
+  float q_scale, k_scale, v_scale;
   int chunk;          // > 0: chunk-causal (streaming) mask -- query i sees keys j < (i / chunk + 1) * chunk; 0: all keys
   int ablate;         // tuning aid (JV_ABLATE): 1 no K/V loads, 2 no split + LDS stores, 4 no barriers, 8 no PV, 16 no QK^T, 32 no softmax
 };

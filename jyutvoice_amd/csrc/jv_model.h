@@ -57,7 +57,11 @@ struct GemmW {
 struct LnW { const float* g = nullptr; const float* b = nullptr; };
 
 struct ResnetW { GemmW block1, block2, res; LnW ln1, ln2; };
-struct BtbW { LnW n1, n3; GemmW qkv, out, ff1, ff2; };
+struct BtbW {
+  LnW n1, n3;
+  GemmW qkv, out, ff1, ff2;
+  float q_scale = 0.f, k_scale = 0.f, v_scale = 0.f;   // fp16x3 attention (AttnArgs), from the load-time bounds; 0 = bf16x6
+};
 struct EstimatorW {
   GemmW time1, time2, temb_all;
   ResnetW res[EST_NRES];                 // 0 = down, 1..12 = mid, 13 = up

@@ -395,22 +395,21 @@ struct Packer {
     }
     return m;
   }
-  // attach the fp16x3 planes; returns max over rows [r0, r1) of sum_k |w| (for the bound of what this layer produces)
-  float half3(GemmW& g, int r0 = 0, int r1 = -1) {
-    if (!g.w || rc != JV_OK || g.ntaps != 1) return NAN;
+  // attach the fp16x3 planes; returns the device vector of the rows' L1 norms (for the bound of what the layer produces)
+  const float* half3(GemmW& g) {
+    if (!g.w || rc != JV_OK || g.ntaps != 1) return nullptr;
     const long n = (long)g.n_rows * g.ldw;
     float* d = alloc((size_t)n + 8);             // 2 planes x 2 bytes
     float* cs = alloc((size_t)g.n_rows);
     float* stats = alloc((size_t)2 * g.n_rows);
-    if (!d || !cs || !stats) return NAN;
+    if (!d || !cs || !stats) return nullptr;
     if (split2h_planes(g.w, g.n_rows, g.ldw, stats, reinterpret_cast<unsigned short*>(d), cs, st) != JV_OK) {
       rc = JV_ERR_HIP;
-      return NAN;
+      return nullptr;
     }
     g.w2 = reinterpret_cast<const unsigned short*>(d);
     g.colscale = cs;
-    if (r1 < 0) r1 = g.n_rows;
-    return host_maxabs(stats + g.n_rows + r0, r1 - r0);
+    return stats + g.n_rows;
   }
   // conv weight [cout][cin][k] (device, plain) -> GemmW with cin padded to cinp
   GemmW conv(const float* w, int cout, int cin, int k, int cinp, const float* bias) {
@@ -578,13 +577,21 @@ int finalize_model(Context& c, int model, hipStream_t st) {
         // returns convex combinations of its V rows; |gelu(x)| <= |x|.
         const float b1 = 16.f * pk.host_maxabs(w.n1.g, EST_CH) + pk.host_maxabs(w.n1.b, EST_CH);
         const float b3 = 16.f * pk.host_maxabs(w.n3.g, EST_CH) + pk.host_maxabs(w.n3.b, EST_CH);
-        const float l1_v = pk.half3(w.qkv, 2 * EST_INNER, 3 * EST_INNER);
+        const float* l1_qkv = pk.half3(w.qkv);
         (void)pk.half3(w.out);
-        const float l1_ff1 = pk.half3(w.ff1);
+        const float* l1_ff1v = pk.half3(w.ff1);
         (void)pk.half3(w.ff2);
+        const float l1_q = pk.host_maxabs(l1_qkv, EST_INNER), l1_k = pk.host_maxabs(l1_qkv ? l1_qkv + EST_INNER : nullptr, EST_INNER);
+        const float l1_v = pk.host_maxabs(l1_qkv ? l1_qkv + 2 * EST_INNER : nullptr, EST_INNER);
+        const float l1_ff1 = pk.host_maxabs(l1_ff1v, EST_FF);
         w.qkv.a_scale = h3_scale_for_bound(b1);
         w.ff1.a_scale = h3_scale_for_bound(b3);
         w.ff2.a_scale = h3_scale_for_bound(l1_ff1 * b3 + pk.host_maxabs(w.ff1.bias, EST_FF));
+        // attention: q (with the kernel's log2(e)/8 folded in), k, v are rows of the qkv Linear (no bias)
+        w.q_scale = h3_scale_for_bound(l1_q * b1 * 0.1803369f);
+        w.k_scale = h3_scale_for_bound(l1_k * b1);
+        w.v_scale = h3_scale_for_bound(l1_v * b1);
+        if (!(w.q_scale > 0.f && w.k_scale > 0.f && w.v_scale > 0.f)) w.q_scale = w.k_scale = w.v_scale = 0.f;
         v_bound = fmaxf(v_bound, l1_v * b1);
         if (!(l1_v * b1 < 1e30f)) v_bound = INFINITY;
       }

@@ -249,6 +249,17 @@ def op_attention(qkv, lens, B, G, S, L):
     return out
 
 
+def op_attention_h3(qkv, lens, B, G, S, L, bounds=None):
+    """fp16x3 attention kernel; bounds = (|q|, |k|, |v|) maxima the caller vouches for (default: measured)"""
+    lib = _lib.load()
+    out = torch.zeros(qkv.shape[0], 512, device=qkv.device)
+    if bounds is None:
+        bounds = tuple(float(qkv[:, o:o + 512].abs().max()) for o in (0, 512, 1024))
+    check(lib.jv_op_attention_h3(_ptr(qkv), _ptr(lens), B, G, S, L, float(bounds[0]), float(bounds[1]), float(bounds[2]),
+                                 _ptr(out), _stream(qkv.device)))
+    return out
+
+
 def op_layernorm(x, g, b, eps=1e-5):
     lib = _lib.load()
     out = torch.empty_like(x)

@@ -322,3 +322,33 @@ def test_h3_weight_dma_race_screen(dev, monkeypatch):
     for i in range(40):
         noise.normal_()
         assert torch.equal(op_linear_h3(A, W, b, a_bound=8.0), first), i
+
+
+@pytest.mark.parametrize("B,L,lens", [(2, 300, [300, 211]), (3, 64, [64, 1, 33]), (1, 512, [512]), (2, 150, [97, 150])])
+def test_h3_attention(dev, B, L, lens):
+    """the fp16x3 attention kernel against fp64, same tolerance as test_attention; bounds loose by 8x as a load-time
+    L1-norm bound would be"""
+    from jyutvoice_amd.engine import op_attention_h3
+    g = torch.Generator().manual_seed(B * 1000 + L + 5)
+    G, gap = 4, 4
+    S = L + gap
+    rows = G + B * S + 8
+    qkv = torch.randn(rows, 1536, generator=g)
+    qkv[:, 512:1024] *= 3.0          # sharper softmax rows
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    bounds = tuple(8.0 * float(qkv[:, o:o + 512].abs().max()) for o in (0, 512, 1024))
+    out = op_attention_h3(qkv.to(dev), lens_t.to(dev), B, G, S, L, bounds).cpu()
+    for b in range(B):
+        blk = qkv[G + b * S: G + b * S + L].double()
+        q, k, v = (blk[:, i * 512:(i + 1) * 512].view(L, 8, 64).transpose(0, 1) for i in range(3))
+        s = q @ k.transpose(1, 2) / 8.0
+        s[:, :, lens[b]:] = -1e10
+        o = (torch.softmax(s, -1) @ v).transpose(0, 1).reshape(L, 512)
+        got = out[G + b * S: G + b * S + L].double()
+        assert float((got - o).abs().max()) < 5e-6, b
+    # values AT the bound: finite, same tolerance
+    qkv2 = qkv.clone()
+    big = [float(qkv[:, o:o + 512].abs().max()) for o in (0, 512, 1024)]
+    out2 = op_attention_h3(qkv2.to(dev), lens_t.to(dev), B, G, S, L, tuple(big)).cpu()
+    assert torch.isfinite(out2).all()
+    assert float((out2 - out).abs().max()) < 5e-6

@@ -2,7 +2,7 @@
 """Micro-benchmark of the conv_gemm / attention kernels on the estimator's shapes at C3 (M = 19.3K rows).
     JV_TILE=0|1|2 python tools/gemm_bench.py      (tuning aid; prints TFLOP/s per shape)
 
-Switches: JV_ONLY=qkv|ff1|ff2|out|res|conv3|attn (shape filter), JV_ATTN_L=frames (one attention length), JV_M=rows, JV_OP_X6=1 (bf16x6 main loop), JV_TILE (force tile),
+Switches: JV_ONLY=qkv|ff1|ff2|out|res|conv3|attn (shape filter), JV_ATTN_L=frames (one attention length), JV_M=rows, JV_OP_X6=1 (bf16x6 main loop), JV_OP_H3=1 (fp16x3 main loop, linears), JV_TILE (force tile),
 JV_ATTN_FP32=1.  With a tuning build (JV_TUNING=1 python -m jyutvoice_amd.build --force): JV_ABLATE=bits (1 no global loads in the
 loop, 2 no LDS stores, 4 no barrier, 16 no epilogue, 64 no output stores, 256 slab epilogue) and JV_STAMPS=1 (per-workgroup
 s_memtime phase breakdown on stderr)."""
@@ -15,7 +15,7 @@ os.environ.setdefault("JV_DYNAMIC_ENV", "1")
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from jyutvoice_amd.engine import op_attention, op_conv_gemm  # noqa: E402
+from jyutvoice_amd.engine import op_attention, op_conv_gemm, op_linear_h3  # noqa: E402
 
 dev = torch.device("cuda:0")
 M = int(os.environ.get("JV_M", 4 + 64 * 304))
@@ -49,7 +49,11 @@ for name, cin, n, taps, ln in shapes:
     if ln:
         kw["ln"] = (torch.ones(n, device=dev), torch.zeros(n, device=dev))
         kw["act"] = "mish"
-    t = timeit(lambda: op_conv_gemm(A, W, b, ntaps=taps, tap_row0=-(taps - 1), M=M, **kw))
+    if os.environ.get("JV_OP_H3") and taps == 1 and not ln:      # fp16x3 main loop (linears only)
+        A = A[:M].contiguous()
+        t = timeit(lambda: op_linear_h3(A, W, b, a_bound=8.0))
+    else:
+        t = timeit(lambda: op_conv_gemm(A, W, b, ntaps=taps, tap_row0=-(taps - 1), M=M, **kw))
     print(f"{name:22s} {t * 1e6:8.1f} us  {2.0 * M * n * taps * cin / t / 1e12:7.1f} TF")
 for L in ((int(os.environ["JV_ATTN_L"]),) if os.environ.get("JV_ATTN_L") else (300, 512)):
     if only and only != "attn":

@@ -12,11 +12,12 @@ out = sys.argv[1]
 
 
 def short(name):
-    m = re.search(r"conv_gemm_x6_kernel<(\d+), (\d+), \d+, \d+, (\d), (\d), (\d)(?:, \d+)?>", name)
+    m = re.search(r"conv_gemm_x6_kernel<(\d+), (\d+), \d+, \d+, (\d), (\d), (\d)(?:, (\d+))?(?:, (\d+))?>", name)
     if m:
         pro = {"0": "", "1": ",snake", "2": ",lrelu"}[m.group(3)]
         epi = {"0": "", "1": ",gelu", "2": ",res", "4": ",generic"}.get(m.group(4), "")
-        return f"conv_gemm_x6<{m.group(1)}x{m.group(2)}{pro}{epi}>"
+        fam = "conv_gemm_h3" if m.group(7) == "2" else "conv_gemm_x6"      # last parameter: planes per operand
+        return f"{fam}<{m.group(1)}x{m.group(2)}{pro}{epi}>"
     m = re.search(r"conv_gemm_kernel<(\d+), (\d+), \d+, \d+, \d+, (\d), (\d)>", name)
     if m:
         pro = {"0": "", "1": ",snake", "2": ",lrelu"}[m.group(3)]
