@@ -151,7 +151,9 @@ int jv_hift_decode(jv_context* ctx, const float* mel, const float* s, const int3
  * jv_op_attention: softmax(q k^T / 8 over keys < lens[b]) v for qkv rows [G + b*S + t][1536], 8 heads x 64.
  * jv_op_layernorm: rows [rows, C].
  * jv_op_linear_h3: out = act(A W^T + bias) (+ res) through the fp16x3 main loop (jv_flow_set_contraction); A [rows, K],
- *                  W [N, K], a_bound = the caller's bound on |A| (the kernel's contract: |A| <= a_bound).
+ *                  W [N, K], a_bound = the caller's bound on |A| (the kernel's contract: |A| <= a_bound); presplit = 1:
+ *                  A is first written as fp16 planes (what LayerNorm / attention / the GELU epilogue do in the estimator)
+ *                  and both operands travel by LDS-DMA; 2: reuse the previous call's planes (timing only).
  * jv_op_attention_h3: jv_op_attention through the fp16x3 kernel, with the caller's bounds on |q|, |k|, |v|. */
 int jv_op_conv_gemm(const float* A, int64_t a_rows, int M, int Cin, int ntaps, int tap_row0, int dil, const float* W, int N,
                     const float* bias, int act, int prologue, const float* alpha, float slope, const float* ln_g,
@@ -160,7 +162,7 @@ int jv_op_attention(const float* qkv, const int32_t* lens, int B, int G, int S, 
 int jv_op_attention_h3(const float* qkv, const int32_t* lens, int B, int G, int S, int L, float q_bound, float k_bound,
                        float v_bound, float* out, void* stream);
 int jv_op_linear_h3(const float* A, int64_t rows, int M, int K, const float* W, int N, const float* bias, int act,
-                    const float* res, float a_bound, float* out, void* stream);
+                    const float* res, float a_bound, int presplit, float* out, void* stream);
 int jv_op_layernorm(const float* x, const float* g, const float* b, float eps, int64_t rows, int C, float* out,
                     void* stream);
 

@@ -13,6 +13,7 @@ namespace jv {
 int split3_planes(const float* src, unsigned short* dst, long n, hipStream_t st);   // registry.hip
 int split2h_planes(const float* src, int rows, int ld, float* stats, unsigned short* dst, float* colscale, hipStream_t st);
 float h3_scale_for_bound(float bound);
+int split2h_rows(const float* x, long ld, unsigned short* dst, long plane, long rows, int C, float scale, hipStream_t st);   // rowops.hip
 
 static thread_local std::string g_last_error;
 
@@ -239,7 +240,7 @@ int jv_op_conv_gemm(const float* A, int64_t a_rows, int M, int Cin, int ntaps, i
 
 // y = act(A W^T + bias) (+ res) through the fp16x3 main loop; a_bound: the caller's proven bound on |A| (test hook)
 int jv_op_linear_h3(const float* A, int64_t rows, int M, int K, const float* W, int N, const float* bias, int act,
-                    const float* res, float a_bound, float* out, void* stream) {
+                    const float* res, float a_bound, int presplit, float* out, void* stream) {
   static bool inited = false;
   if (!inited) {
     JV_TRY(jv::conv_gemm_init());
@@ -267,6 +268,18 @@ int jv_op_linear_h3(const float* A, int64_t rows, int M, int K, const float* W, 
   a.W = W; a.ldw = K; a.n_rows_w = N; a.N = N; a.bias = bias; a.out = out; a.ldo = N; a.act = act;
   a.res1 = res; a.ldr1 = N;
   a.W2 = planes; a.w2_plane = (long)n; a.colscale = cs; a.a_scale = sc;
+  if (presplit) {      // A as fp16 planes written by a producer kernel; 2 = reuse the planes of the previous call (timing)
+    static unsigned short* ap = nullptr;
+    static size_t acap = 0;
+    const size_t an = (size_t)rows * K;
+    if (an * 4 > acap) {
+      if (ap) (void)hipFree(ap);
+      JV_HIP(hipMalloc(reinterpret_cast<void**>(&ap), an * 4));
+      acap = an * 4;
+    }
+    if (presplit == 1) JV_TRY(jv::split2h_rows(A, K, ap, (long)an, rows, K, sc, st));
+    a.A2 = ap; a.a2_plane = (long)an; a.lda2 = K;
+  }
   return jv::conv_gemm(a, 1, st);
 }
 

@@ -234,6 +234,7 @@ void conv_gemm_defaults(ConvGemmArgs& a) {
   a.tap_dil = 1;
   a.out_scale = 1.f;
   a.a_scale = 1.f;
+  a.out2_scale = 1.f;
   a.nb2 = 1;
   a.ln_eps = 1e-5f;
 }

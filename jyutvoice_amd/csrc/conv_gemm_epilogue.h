@@ -22,7 +22,8 @@ __device__ __forceinline__ void epilogue_passes(F& f) {      // f(0), f(1), ... 
   }
 }
 
-// EPI: bit 0 = exact GELU, bit 1 = + res1 (lean float4 epilogues); 4 = generic (any activation, mask, row vector,
+// EPI: bit 0 = exact GELU, bit 1 = + res1, bit 3 = write fp16 planes of value * out2_scale to p.out2 instead of fp32 rows
+// (lean float4 epilogues); 4 = generic (any activation, mask, row vector,
 // second residual, scaling, accumulation, ragged N).  Must be entered by all 256 threads after the main loop's last
 // barrier; `smem` is reused for the slabs.
 // SC: the accumulators are first multiplied by colscale[n] / a_scale (fp16x3 main loop, ConvGemmArgs::W2).
@@ -73,7 +74,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
     if constexpr (EPI != 4) {
       // lean path (host guarantees N % 4 == 0, 16-byte aligned rows, no mask / row vector / second residual / scaling):
       // out = act(acc + bias) (+ res1).  All residual loads of the pass are issued before any arithmetic.
-      constexpr bool E_GELU = (EPI & 1) != 0, E_RES = (EPI & 2) != 0;
+      constexpr bool E_GELU = (EPI & 1) != 0, E_RES = (EPI & 2) != 0, E_PL = (EPI & 8) != 0;
       const int mrow = m0 + wm * WM + mt * 32 + rsub;
       f32x4 x[NIT], r[NIT];
 #pragma unroll
@@ -93,6 +94,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
           for (int e = 0; e < 4; ++e) t[e] = 0.5f * t[e] * (1.f + erff(t[e] * 0.70710678118654752440f));
         }
         if constexpr (E_RES) t += r[it];
+        if constexpr (E_PL) {
+          if (nin && mrow + it * RPI < p.M) {
+            const Split2 s0 = split2h_pair(t[0] * p.out2_scale, t[1] * p.out2_scale);
+            const Split2 s1 = split2h_pair(t[2] * p.out2_scale, t[3] * p.out2_scale);
+            unsigned short* o2 = p.out2 + (long)(mrow + it * RPI) * p.ldo2 + n;
+            typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u32x2_*>(o2) = u32x2_{s0.h, s1.h};
+            *reinterpret_cast<u32x2_*>(o2 + p.out2_plane) = u32x2_{s0.l, s1.l};
+          }
+        } else
         if (nin && mrow + it * RPI < p.M && !JV_ABLATE(p, 64)) *reinterpret_cast<f32x4*>(ob + (long)(it * RPI) * p.ldo) = t;
       }
       return;

@@ -75,7 +75,9 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int r32 = lane & 31, half = lane >> 5;
   constexpr bool AQ = NA2 == 0;                  // quarter-row staging
-  constexpr int NR = AQ ? 1 : NA2, NG = AQ ? 1 : 2;
+  constexpr bool APL = NA2 == 3;                 // A arrives as fp16 planes (p.A2) by LDS-DMA, double-buffered like W
+  static_assert(!APL || (NP == 2 && NWB == 2 && PRO == PRO_NONE), "pre-split A: fp16x3, two buffers, plain prologue");
+  constexpr int NR = (AQ || APL) ? 1 : NA2, NG = AQ ? 1 : 2;
   const int arow = AQ ? tid >> 2 : tid >> 1, kpart = AQ ? tid & 3 : tid & 1;
   const int koff = (AQ ? 8 : 16) * kpart;
 
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
   const int ntaps = p.ntaps, dil = p.tap_dil;
   const int win = BM + (ntaps - 1) * dil;
   unsigned char* const ldsA = reinterpret_cast<unsigned char*>(smem);            // [NP][win][64 B]
-  unsigned char* const ldsW = ldsA + NP * win * ROWB;                            // [NWB][NP][BN][64 B]
+  unsigned char* const ldsW = ldsA + (APL ? 2 : 1) * NP * win * ROWB;            // [NWB][NP][BN][64 B]
 
   // Rows outside the matrix or masked out read as zero.  Instead of predicating every load of the loop (exec-mask
   // branches, ~16 scalar instructions per step), such a row's pointer is aimed once at a page of zeros and its per-step
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
   const float* asrc[NR];
   int astep[NR];
 #pragma unroll
-  for (int i = 0; i < NR; ++i) {
+  for (int i = 0; i < (APL ? 0 : NR); ++i) {
     const int r = arow + 128 * i;
     const long ar = (long)m0 + p.tap_row0 + r;
     bool ok = (r < win) && (ar >= 0) && (ar < p.a_rows);
@@ -199,6 +201,23 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
     }
   };
 
+  // pre-split A: NP * BM / 16 one-KiB pieces per step, rows past the buffer clamped (their outputs are never stored)
+  auto dma_A = [&](int kb, int buf) {
+    constexpr int PIECES = NP * BM / 16;
+#pragma unroll
+    for (int i = 0; i < PIECES / 4; ++i) {
+      const int pc = wave + 4 * i;
+      const int plane = pc / (BM / 16), g16 = pc % (BM / 16);
+      const int row = g16 * 16 + (lane >> 2);
+      const int kslot = (lane & 3) ^ swz(row);
+      const long ar = min((long)m0 + row, p.a_rows - 1);
+      const unsigned short* src = p.A2 + (long)plane * p.a2_plane + ar * p.lda2 + kb + 8 * kslot;
+      unsigned char* dst = ldsA + ((buf * NP + plane) * BM + g16 * 16) * ROWB;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -209,27 +228,31 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
 
   const int nchunks = p.Cin >> 5;
   const int nsteps = nchunks * ntaps;
-  load_A(0);
+  if constexpr (APL) dma_A(0, 0);
+  else load_A(0);
   if constexpr (NWB == 2) dma_W(0, 0);
   if (JV_STAMP(p)) t_loop = __builtin_amdgcn_s_memtime();
   int c = 0, j = 0;
   for (int s = 0; s < nsteps; ++s) {
     if (!JV_ABLATE(p, 4)) __syncthreads();      // every wave is done reading the previous step's LDS images
     if constexpr (NWB == 1) dma_W(j * p.Cin + c * 32, 0);
-    if (!JV_ABLATE(p, 2)) {
-      if (j == 0) store_A(c * 32);
+    if constexpr (!APL) {
+      if (!JV_ABLATE(p, 2)) {
+        if (j == 0) store_A(c * 32);
+      }
+      // __syncthreads() drains vmcnt before its barrier, which retires this step's weight DMA in every wave: LDS-DMA
+      // data may be read only after the issuing waves' vmcnt wait AND a barrier the reader has passed
+      if (!JV_ABLATE(p, 4)) __syncthreads();
     }
-    // __syncthreads() drains vmcnt before its barrier, which retires this step's weight DMA in every wave: LDS-DMA data
-    // may be read only after the issuing waves' vmcnt wait AND a barrier the reader has passed
-    if (!JV_ABLATE(p, 4)) __syncthreads();
     int j2 = j + 1, c2 = c;
     if (j2 == ntaps) { j2 = 0; c2 = c + 1; }
     if (s + 1 < nsteps && !JV_ABLATE(p, 1)) {
-      if (j2 == 0) load_A(c2 * 32);
+      if constexpr (APL) dma_A(c2 * 32, (s + 1) & 1);      // one barrier per step: both operands land a step ahead
+      else if (j2 == 0) load_A(c2 * 32);
       // buffer (s + 1) & 1 was last read in step s - 1, which every wave finished before the barriers above
       if constexpr (NWB == 2) dma_W(j2 * p.Cin + c2 * 32, (s + 1) & 1);
     }
-    const unsigned char* la = ldsA + (wm * WM + r32 + j * dil) * ROWB;
+    const unsigned char* la = ldsA + (APL ? (s & 1) * NP * win * ROWB : 0) + (wm * WM + r32 + j * dil) * ROWB;
     const unsigned char* lw = ldsW + (NWB == 2 ? (s & 1) * NP * BN * ROWB : 0) + (wn * WN + r32) * ROWB;
     // WM, WN and the 32-row fragment steps are multiples of 16 rows, so only r32 (and the tap's row offset) enter the keys
     const int swzw = swz(r32), swza = swz(r32 + j * dil);
@@ -286,7 +309,7 @@ namespace {
 template <int BM, int BN>
 size_t x6_lds_bytes(const ConvGemmArgs& a, int nwb = 1) {
   const int win = BM + (a.ntaps - 1) * a.tap_dil;
-  return (size_t)(a.W2 ? 2 : 3) * (win + nwb * BN) * ROWB;
+  return (size_t)(a.W2 ? 2 : 3) * ((a.A2 ? 2 : 1) * win + nwb * BN) * ROWB;
 }
 
 template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int NWB, int NP>
@@ -342,7 +365,8 @@ int x6_launch4(const ConvGemmArgs& a, hipStream_t st) {
   if (prof) {
     static const std::string name = std::string(NP == 2 ? "conv_gemm_h3<" : "conv_gemm_x6<") + std::to_string(BM) + "x" + std::to_string(BN) +
                                     (PRO == PRO_SNAKE ? ",snake" : PRO == PRO_LRELU ? ",lrelu" : "") +
-                                    (EPI == 1 ? ",gelu" : EPI == 2 ? ",res" : EPI == 4 ? ",generic" : "") + ">";
+                                    (NA2 == 3 ? ",dmaA" : "") +
+                                    ((EPI & 7) == 1 ? ",gelu" : EPI == 2 ? ",res" : EPI == 4 ? ",generic" : "") + ">";
     const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M);
     const double k = (double)(a.alg_k > 0 ? a.alg_k : a.ntaps * a.Cin);
     const double bytes = 4.0 * (rows * a.Cin + (double)a.N * k + rows * a.N * (1 + (a.res1 ? 1 : 0) + (a.res2 ? 1 : 0)));
@@ -365,6 +389,9 @@ int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
 // the 64x64 tile its fifth workgroup per CU.
 template <int BM, int BN, int WM, int WN, int PRO, int EPI>
 int x6_launch2(const ConvGemmArgs& a, hipStream_t st) {
+  if constexpr (PRO == PRO_NONE) {
+    if (a.A2) return x6_launch4<BM, BN, WM, WN, PRO, EPI, 3, 2, 2>(a, st);      // conv_gemm_x6() checked the preconditions
+  }
   const int win = BM + (a.ntaps - 1) * a.tap_dil;
   if (win > (BM >= 128 ? 256 : 128)) return fail(JV_ERR_ARG, "conv_gemm_x6: window too tall for this tile variant");
   if constexpr (BM >= 128) {
@@ -387,7 +414,9 @@ int x6_launch1(const ConvGemmArgs& a, hipStream_t st) {
                     !a.accumulate && a.out_scale == 1.f;
   if (lean && a.act == ACT_NONE)
     return a.res1 ? x6_launch2<BM, BN, WM, WN, PRO, 2>(a, st) : x6_launch2<BM, BN, WM, WN, PRO, 0>(a, st);
-  if (lean && a.act == ACT_GELU && PRO == PRO_NONE && !a.res1) return x6_launch2<BM, BN, WM, WN, PRO_NONE, 1>(a, st);
+  if (lean && a.act == ACT_GELU && PRO == PRO_NONE && !a.res1)
+    return a.out2 ? x6_launch2<BM, BN, WM, WN, PRO_NONE, 9>(a, st) : x6_launch2<BM, BN, WM, WN, PRO_NONE, 1>(a, st);
+  if (a.out2) return fail(JV_ERR_ARG, "conv_gemm_x6: plane output exists for the lean GELU epilogue only");
   return x6_launch2<BM, BN, WM, WN, PRO, 4>(a, st);
 }
 
@@ -411,6 +440,8 @@ int conv_gemm_x6(const ConvGemmArgs& a0, hipStream_t st) {
     a.W2 = nullptr;
   }
   if (!a.W2 && !a.W3) return fail(JV_ERR_ARG, "conv_gemm_x6: no weight planes");
+  if (a.A2 && (!a.W2 || a.ntaps != 1 || a.rowmask_in || (a.lda2 & 7)))
+    return fail(JV_ERR_ARG, "conv_gemm_x6: pre-split A needs the fp16x3 path, one tap, no input mask, lda2 % 8 == 0");
   const int span = (a.ntaps - 1) * a.tap_dil;
   struct Cand { int bm, bn; double eff; size_t lds; int max_win; };
   // measured on the estimator shapes (tools/gemm_bench.py): the big tile amortises staging and barriers best.  The

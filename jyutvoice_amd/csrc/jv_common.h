@@ -91,6 +91,15 @@ struct ConvGemmArgs {
   long w2_plane;
   const float* colscale;
   float a_scale;
+  // optional with W2 (linears, ntaps = 1): A already split by its producer -- two fp16 planes [2][a_rows][lda2] of
+  // A * a_scale (LayerNorm, attention and the GELU epilogue write them, same bytes as the fp32 rows); both operands then
+  // reach LDS by LDS-DMA and the main loop has no VALU work and one barrier per step
+  const unsigned short* A2;
+  long a2_plane, lda2;
+  // optional output as planes instead of fp32 rows: out2[0/1][m][ldo2] = fp16 split of value * out2_scale (lean epilogues)
+  unsigned short* out2;
+  long out2_plane, ldo2;
+  float out2_scale;
   int ldw;
   int n_rows_w;    // rows of W that may be read (>= N, zero padded)
   int N;           // valid output columns

@@ -230,15 +230,16 @@ def op_conv_gemm(A, W, bias=None, ntaps=1, tap_row0=0, dil=1, M=None, act="none"
     return out
 
 
-def op_linear_h3(A, W, bias=None, act="none", res=None, a_bound=None):
-    """fp16x3 main loop (jv_flow_set_contraction): A [rows, K], W [N, K]; a_bound >= max |A| (default: measured)."""
+def op_linear_h3(A, W, bias=None, act="none", res=None, a_bound=None, presplit=0):
+    """fp16x3 main loop (jv_flow_set_contraction): A [rows, K], W [N, K]; a_bound >= max |A| (default: measured);
+    presplit=1: A goes through fp16 planes and LDS-DMA as in the estimator (2: reuse the previous planes, timing only)."""
     lib = _lib.load()
     rows, K = A.shape
     N = W.shape[0]
     out = torch.empty(rows, N, device=A.device)
     bound = float(A.abs().max()) if a_bound is None else float(a_bound)
-    check(lib.jv_op_linear_h3(_ptr(A), rows, rows, K, _ptr(W), N, _ptr(bias), _lib.ACT[act], _ptr(res), bound, _ptr(out),
-                              _stream(A.device)))
+    check(lib.jv_op_linear_h3(_ptr(A), rows, rows, K, _ptr(W), N, _ptr(bias), _lib.ACT[act], _ptr(res), bound, int(presplit),
+                              _ptr(out), _stream(A.device)))
     return out
 
 

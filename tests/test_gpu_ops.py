@@ -352,3 +352,28 @@ def test_h3_attention(dev, B, L, lens):
     out2 = op_attention_h3(qkv2.to(dev), lens_t.to(dev), B, G, S, L, tuple(big)).cpu()
     assert torch.isfinite(out2).all()
     assert float((out2 - out).abs().max()) < 5e-6
+
+
+@pytest.mark.parametrize("tile", ["0", "2", "3"])
+def test_h3_presplit_operand_is_bit_identical(dev, monkeypatch, tile):
+    """A written as fp16 planes by a producer kernel and fetched by LDS-DMA (what the estimator does) gives the same bits as
+    the in-kernel split, on ragged shapes, for the tiles the estimator uses; plus the weight/operand DMA race screen"""
+    from jyutvoice_amd.engine import op_linear_h3
+    monkeypatch.setenv("JV_TILE", tile)
+    g = torch.Generator().manual_seed(240 + int(tile))
+    M, K, N = 1000, 512, 392
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    for kw in ({}, {"act": "gelu"}, {"res": res}):
+        ref = op_linear_h3(A, W, b, a_bound=8.0, **kw)
+        got = op_linear_h3(A, W, b, a_bound=8.0, presplit=1, **kw)
+        assert torch.equal(ref, got), kw
+    want = A.double().cpu() @ W.double().cpu().T + b.double().cpu()
+    first = op_linear_h3(A, W, b, a_bound=8.0, presplit=1)
+    assert rel_err(first, want) < 2e-6
+    noise = torch.empty(64 << 20, device=dev)
+    for i in range(30):
+        noise.normal_()
+        assert torch.equal(op_linear_h3(A, W, b, a_bound=8.0, presplit=1), first), i

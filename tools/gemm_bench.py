@@ -51,7 +51,11 @@ for name, cin, n, taps, ln in shapes:
         kw["act"] = "mish"
     if os.environ.get("JV_OP_H3") and taps == 1 and not ln:      # fp16x3 main loop (linears only)
         A = A[:M].contiguous()
-        t = timeit(lambda: op_linear_h3(A, W, b, a_bound=8.0))
+        if os.environ.get("JV_H3_DMA_A"):       # A pre-split into fp16 planes once, both operands by LDS-DMA
+            op_linear_h3(A, W, b, a_bound=8.0, presplit=1)
+            t = timeit(lambda: op_linear_h3(A, W, b, a_bound=8.0, presplit=2))
+        else:
+            t = timeit(lambda: op_linear_h3(A, W, b, a_bound=8.0))
     else:
         t = timeit(lambda: op_conv_gemm(A, W, b, ntaps=taps, tap_row0=-(taps - 1), M=M, **kw))
     print(f"{name:22s} {t * 1e6:8.1f} us  {2.0 * M * n * taps * cin / t / 1e12:7.1f} TF")
