@@ -75,6 +75,7 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   c.max_batch = max_batch;
   c.step_graphs = getenv("JV_STEP_GRAPH") != nullptr;
   c.exact_range = getenv("JV_EXACT_RANGE") != nullptr;
+  c.dma_a = getenv("JV_DMA_A") != nullptr;
   c.max_frames = max_frames;
   c.max_tokens = max_tokens;
   jv::build_registry(c);
@@ -192,7 +193,10 @@ int jv_flow_set_graph(jv_context* ctx, int on) {
 
 int jv_flow_set_contraction(jv_context* ctx, int exact_range) {
   if (!ctx) return jv::fail(JV_ERR_ARG, "null context");
-  if (ctx->c.exact_range != (exact_range != 0)) jv::flow_graphs_drop(ctx->c);      // captured steps hold the old kernels
+  if (ctx->c.exact_range != (exact_range != 0)) {
+    jv::flow_graphs_drop(ctx->c);                  // captured steps hold the old kernels
+    jv::flow_ws_forget_attention(ctx->c, nullptr);   // that buffer holds fp32 rows in one mode, fp16 planes in the other
+  }
   ctx->c.exact_range = exact_range != 0;
   return JV_OK;
 }

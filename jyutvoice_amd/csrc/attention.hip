@@ -466,6 +466,22 @@ __global__ __launch_bounds__(64 * NW, WPE) void attn64_x6_kernel(const AttnArgs 
   if (active && qi < p.L) {
     const float inv = l_run > 0.f ? (1.0f / vsc) / l_run : 0.f;
     float* dst = p.out + (rowbase + qi) * p.ldo + h * 64 + 4 * half;
+    if (p.out2) {      // wave-uniform: the consumer is an fp16x3 GEMM that takes its A operand pre-split
+      unsigned short* d2 = p.out2 + (rowbase + qi) * p.ldo + h * 64 + 4 * half;
+      const float sc = p.out2_scale;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const Split2 a0 = split2h_pair(o0[4 * g] * inv * sc, o0[4 * g + 1] * inv * sc);
+        const Split2 a1 = split2h_pair(o0[4 * g + 2] * inv * sc, o0[4 * g + 3] * inv * sc);
+        const Split2 c0 = split2h_pair(o1[4 * g] * inv * sc, o1[4 * g + 1] * inv * sc);
+        const Split2 c1 = split2h_pair(o1[4 * g + 2] * inv * sc, o1[4 * g + 3] * inv * sc);
+        *reinterpret_cast<u32x2*>(d2 + 8 * g) = u32x2{a0.h, a1.h};
+        *reinterpret_cast<u32x2*>(d2 + 8 * g + p.out2_plane) = u32x2{a0.l, a1.l};
+        *reinterpret_cast<u32x2*>(d2 + 32 + 8 * g) = u32x2{c0.h, c1.h};
+        *reinterpret_cast<u32x2*>(d2 + 32 + 8 * g + p.out2_plane) = u32x2{c0.l, c1.l};
+      }
+      return;
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 a = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};

@@ -179,29 +179,48 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     if (c.exact_range || !m.w2 || !(m.a_scale > 0.f)) return;
     a.W2 = m.w2; a.w2_plane = (long)m.n_rows * m.ldw; a.colscale = m.colscale; a.a_scale = m.a_scale;
   };
+  // ... and then take their A operand as the fp16 planes their producer wrote into the same buffer (same bytes as fp32)
+  const long R = (long)w.rows_alloc;
+  auto pre = [&](const GemmW& m) { return c.dma_a && !c.exact_range && m.w2 && m.a_scale > 0.f; };
+  auto planes_in = [&](ConvGemmArgs& a, float* buf, int C) {
+    a.A2 = reinterpret_cast<const unsigned short*>(buf); a.a2_plane = R * C; a.lda2 = C;
+  };
+  auto ln_to = [&](const LnW& n, const GemmW& m, const float* h) -> int {
+    if (pre(m)) return layernorm256_planes(h, reinterpret_cast<unsigned short*>(w.ln), R * 256, m.a_scale, n.g, n.b, 1e-5f, g.M, st);
+    return layernorm_rows(h, nullptr, w.ln, n.g, n.b, 1e-5f, g.M, 256, nullptr, st);
+  };
   auto btb = [&](const BtbW& b, float* h, float* out, int ldo) -> int {
-    JV_TRY(layernorm_rows(h, nullptr, w.ln, b.n1.g, b.n1.b, 1e-5f, g.M, 256, nullptr, st));
+    JV_TRY(ln_to(b.n1, b.qkv, h));
     ConvGemmArgs a = base_args(g, w.ln, 256, b.qkv, w.qkv, 1536);
     h3(a, b.qkv);
+    if (pre(b.qkv)) planes_in(a, w.ln, 256);
     JV_TRY(conv_gemm(a, 1, st));
     AttnArgs at{};
     at.qkv = w.qkv; at.ld = 1536; at.k_off = 512; at.v_off = 1024; at.out = w.att; at.ldo = 512;
     at.B = B2; at.H = EST_HEADS; at.G = FLOW_G; at.S = g.S; at.L = g.T; at.lens = w.lens2;
     at.chunk = c.attn_chunk;
     if (!c.exact_range && b.q_scale > 0.f) { at.q_scale = b.q_scale; at.k_scale = b.k_scale; at.v_scale = b.v_scale; }
+    if (pre(b.out)) { at.out2 = reinterpret_cast<unsigned short*>(w.att); at.out2_plane = R * 512; at.out2_scale = b.out.a_scale; }
     JV_TRY(attention64(at, st));
     a = base_args(g, w.att, 512, b.out, h, 256);
     a.res1 = h; a.ldr1 = 256;
     h3(a, b.out);
+    if (pre(b.out)) planes_in(a, w.att, 512);
     JV_TRY(conv_gemm(a, 1, st));
-    JV_TRY(layernorm_rows(h, nullptr, w.ln, b.n3.g, b.n3.b, 1e-5f, g.M, 256, nullptr, st));
+    JV_TRY(ln_to(b.n3, b.ff1, h));
     a = base_args(g, w.ln, 256, b.ff1, w.ff, 1024);
     a.act = ACT_GELU;
     h3(a, b.ff1);
+    if (pre(b.ff1)) planes_in(a, w.ln, 256);
+    if (pre(b.ff2) && a.W2) {      // the GELU epilogue writes ff2's operand (plane output exists on the fp16x3 lean path)
+      a.out2 = reinterpret_cast<unsigned short*>(w.ff); a.out2_plane = R * 1024; a.ldo2 = 1024; a.out2_scale = b.ff2.a_scale;
+    }
+    const bool ff_planes = a.out2 != nullptr;
     JV_TRY(conv_gemm(a, 1, st));
     a = base_args(g, w.ff, 1024, b.ff2, out, ldo);
     a.res1 = h; a.ldr1 = 256;
     h3(a, b.ff2);
+    if (ff_planes) planes_in(a, w.ff, 1024);
     return conv_gemm(a, 1, st);
   };
 

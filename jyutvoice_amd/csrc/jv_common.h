@@ -161,6 +161,10 @@ struct AttnArgs {
   // fp16x3 contractions (attention.hip, NP = 2) when q_scale > 0: exact powers of two with |q| log2(e)/8 * q_scale,
   // |k| * k_scale, |v| * v_scale < 65504 PROVEN by the caller; 0 = bf16x6, any fp32 operand
   float q_scale, k_scale, v_scale;
+  // optional: the result as two fp16 planes of value * out2_scale (out2[0/1][row][ldo]) instead of fp32 rows
+  unsigned short* out2;
+  long out2_plane;
+  float out2_scale;
   int chunk;          // > 0: chunk-causal (streaming) mask -- query i sees keys j < (i / chunk + 1) * chunk; 0: all keys
   int ablate;         // tuning aid (JV_ABLATE): 1 no K/V loads, 2 no split + LDS stores, 4 no barriers, 8 no PV, 16 no QK^T, 32 no softmax
 };
@@ -170,5 +174,7 @@ int attention64(const AttnArgs& a, hipStream_t st);
 // out = LayerNorm_C(x (+ add)) * g + b, optional ReLU, rows with rowmask_out == 0 written as zero
 int layernorm_rows(const float* x, const float* add, float* out, const float* g, const float* b, float eps, long rows,
                    int C, const unsigned char* rowmask_out, hipStream_t st, int relu = 0);
+int layernorm256_planes(const float* x, unsigned short* out2, long plane, float scale, const float* g, const float* b, float eps,
+                        long rows, hipStream_t st);
 
 }  // namespace jv

@@ -121,6 +121,8 @@ struct Context {
   PromptW prompt;
   float* noise = nullptr;        // [80][15000] fixed CFM noise (device), supplied by the host
   bool noise_loaded = false;
+  bool dma_a = false;            // JV_DMA_A=1: fp16x3 linears take their A operand pre-split from the producer (measured slower
+                                 // in the pipeline than the in-kernel split; kept as a tested alternative)
   bool exact_range = false;      // true: bf16x6 everywhere (jv_flow_set_contraction); false: fp16x3 where the range is proven
   bool step_graphs = false;      // replay the Euler step as a captured hipGraph (jv_flow_set_graph; never under the profiler)
   int attn_chunk = 0;            // > 0: streaming (chunk-causal) estimator attention, in frames (jv_flow_set_streaming)
@@ -143,6 +145,7 @@ int ws_alloc(Context& c, size_t bytes, void** out);
 
 // flow.hip
 int flow_ws_create(Context& c);
+void flow_ws_forget_attention(Context& c, hipStream_t st);   // zero the attention buffer (new weights / contraction mode)
 void flow_graphs_drop(Context& c);   // forget captured Euler-step graphs (weights or workspace pointers changed)
 int flow_estimator(Context& c, const float* x, const int* lens_dev, const float* mu, const float* t_dev, const float* spks,
                    const float* cond, int B2, int T, float* out, hipStream_t st);

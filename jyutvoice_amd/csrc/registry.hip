@@ -485,7 +485,6 @@ struct Packer {
 }  // namespace
 
 int scale_copy(const float* x, float* y, float s, int n, hipStream_t st);   // promptops.hip
-void flow_ws_forget_attention(Context& c, hipStream_t st);                  // flow.hip
 
 int finalize_model(Context& c, int model, hipStream_t st) {
   for (const RawTensor& t : c.raw)

@@ -13,9 +13,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---- LayerNorm over the channel axis of a row buffer (optionally of x + add) -------------------
 // One wave per row; two-pass (mean, then centred sum of squares) entirely in registers for C <= 1024.
 // C == 256 fast path: one wave handles 4 rows at once (4 independent 16-byte loads per lane in flight), the rest as below
+// PL: the result leaves as two fp16 planes of value * scale (out2[0/1][row][256], the pre-split A operand of the
+// fp16x3 GEMM that consumes it -- same bytes as the fp32 row) instead of fp32
+template <bool PL>
 __global__ __launch_bounds__(256) void layernorm256_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                            const float* __restrict__ g, const float* __restrict__ b, float eps,
-                                                           long rows) {
+                                                           long rows, unsigned short* __restrict__ out2, long plane, float scale) {
   const int lane = threadIdx.x & 63;
   const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
   f32x4 v[4];
@@ -45,7 +48,16 @@ __global__ __launch_bounds__(256) void layernorm256_kernel(const float* __restri
     if (row0 + r < rows) {
       const float mean = sum[r] * (1.f / 256.f);
       const float rstd = 1.0f / sqrtf(sq[r] * (1.f / 256.f) + eps);
-      *reinterpret_cast<f32x4*>(out + (row0 + r) * 256 + 4 * lane) = (v[r] - mean) * rstd * gg + bb;
+      const f32x4 y = (v[r] - mean) * rstd * gg + bb;
+      if constexpr (PL) {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const Split2 s0 = split2h_pair(y[0] * scale, y[1] * scale), s1 = split2h_pair(y[2] * scale, y[3] * scale);
+        unsigned short* o2 = out2 + (row0 + r) * 256 + 4 * lane;
+        *reinterpret_cast<u32x2*>(o2) = u32x2{s0.h, s1.h};
+        *reinterpret_cast<u32x2*>(o2 + plane) = u32x2{s0.l, s1.l};
+      } else {
+        *reinterpret_cast<f32x4*>(out + (row0 + r) * 256 + 4 * lane) = y;
+      }
     }
   }
 }
@@ -110,7 +122,8 @@ int layernorm_rows(const float* x, const float* add, float* out, const float* g,
   const bool prof = prof_on();
   if (prof) prof_begin(st);
   if (C == 256 && !add && !rowmask_out && !relu)
-    hipLaunchKernelGGL(layernorm256_kernel, dim3((unsigned)cdivl(rows, 16)), dim3(256), 0, st, x, out, g, b, eps, rows);
+    hipLaunchKernelGGL(layernorm256_kernel<false>, dim3((unsigned)cdivl(rows, 16)), dim3(256), 0, st, x, out, g, b, eps, rows,
+                       nullptr, 0L, 1.f);
   else if (C <= 256)
     hipLaunchKernelGGL((layernorm_rows_kernel<1>), grid, dim3(256), 0, st, x, add, out, g, b, eps, rows, C, rowmask_out, relu);
   else if (C <= 768)
@@ -415,6 +428,19 @@ __global__ void fill_kernel(float* p, float v, long n) {
 int fill(float* p, float v, long n, hipStream_t st) {
   if (n <= 0) return JV_OK;
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, p, v, n);
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+// LayerNorm_256 whose result is written as the pre-split fp16x3 operand (see layernorm256_kernel)
+int layernorm256_planes(const float* x, unsigned short* out2, long plane, float scale, const float* g, const float* b, float eps,
+                        long rows, hipStream_t st) {
+  if (rows <= 0) return JV_OK;
+  const bool prof = prof_on();
+  if (prof) prof_begin(st);
+  hipLaunchKernelGGL(layernorm256_kernel<true>, dim3((unsigned)cdivl(rows, 16)), dim3(256), 0, st, x, nullptr, g, b, eps, rows,
+                     out2, plane, scale);
+  if (prof) prof_end(st, "layernorm", 0.0, 4.0 * rows * 256 * 2);
   JV_HIP(hipGetLastError());
   return JV_OK;
 }

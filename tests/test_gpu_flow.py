@@ -174,3 +174,24 @@ def test_contraction_modes_agree(eng):
     assert md(outs[True][0], outs[False][0]) <= 2e-5
     assert md(outs[True][1], outs[False][1]) <= 1e-4
     assert not torch.equal(outs[True][0], outs[False][0])      # the switch really selects another kernel
+
+
+def test_presplit_operands_equal_in_kernel_split(eng, tts_sd, noise, monkeypatch):
+    """default: each fp16x3 linear splits its fp32 input itself; JV_DMA_A=1: LayerNorm, attention and the GELU epilogue
+    write the fp16 planes and the linear reads both operands by LDS-DMA (no faster in the pipeline -- DESIGN.md -- but kept
+    tested).  Same arithmetic, so the estimator output agrees to the last bits (the two LayerNorm instantiations may
+    contract differently)"""
+    from jyutvoice_amd.engine import JV_MODEL_TTS, Engine
+    g3 = load_golden("G3_estimator")
+    lens = g3["mask"].sum(dim=(1, 2)).to(torch.int32)
+    ref = eng.flow_estimator(g3["x"], lens, g3["mu"], g3["t"], g3["spks"], g3["cond"])
+    monkeypatch.setenv("JV_DMA_A", "1")
+    e2 = Engine("cuda:0", max_batch=4, max_frames=128, max_tokens=64)
+    try:
+        e2.load_state_dict(JV_MODEL_TTS, tts_sd)
+        e2.load_noise(noise)
+        got = e2.flow_estimator(g3["x"], lens, g3["mu"], g3["t"], g3["spks"], g3["cond"])
+    finally:
+        e2.close()
+    assert md(got, g3["out"]) <= 1e-4
+    assert md(ref, got) <= 2e-6
