@@ -23,9 +23,9 @@ def short(name):
         pro = {"0": "", "1": ",snake", "2": ",lrelu"}[m.group(3)]
         epi = {"0": "", "1": ",gelu", "2": ",res", "4": ",generic"}.get(m.group(4), "")
         return f"conv_gemm<{m.group(1)}x{m.group(2)}{pro}{epi}>"
-    m = re.search(r"attn64_x6_kernel<(\d)", name)
+    m = re.search(r"attn64_x6_kernel<(\d)(?:, \d+)?(?:, (\d+))?>", name)
     if m:
-        return f"attn64_x6<{m.group(1)} waves>"
+        return f"{'attn64_h3' if m.group(2) == '2' else 'attn64_x6'}<{m.group(1)} waves>"      # last parameter: planes
     m = re.search(r"conv_gemm_kernelILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+ELb([01])ELi(\d)", name)
     if m:
         pro = {"0": "", "1": ",snake", "2": ",lrelu"}[m.group(4)]
