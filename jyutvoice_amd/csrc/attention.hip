@@ -169,8 +169,9 @@ __global__ __launch_bounds__(64 * NW) void attn64_kernel(const AttnArgs p) {
   }
 }
 
-// ---- bf16x6 variant: same algorithm, contractions as six bf16 MFMA products of 3-plane splits (conv_gemm_x6.hip) -----
-// K is split while it is staged ([3][32 keys][64 d]); V is split AND transposed to [3][64 d][32 keys] so that the PV
+// ---- split-plane variant: same algorithm, contractions as six bf16 MFMA products of 3-plane splits (NP = 3) or, where the
+// caller has proven the range of q, k, v (AttnArgs::q_scale), three fp16 products of 2-plane splits (NP = 2) ------------
+// K is split while it is staged ([NP][32 keys][64 d]); V is split AND transposed to [NP][64 d][32 keys] so that the PV
 // product's A operand is 8 consecutive keys of one d; the key order inside a tile is the
 // one the S^T accumulator already has (register e of lane-half h holds key (e&3)+8(e>>2)+4h), i.e. position p in the V^T
 // row holds key swap_bits23(p): P goes from the softmax to the MFMA with three conversions and no data movement.
@@ -179,7 +180,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// bf16x6 kernel: unpadded tiles [3 planes][32 keys][128 B] and [3][64 d][64 B]; slot keys: a ds_read_b128 lane group
+// unpadded tiles [NP planes][32 keys][128 B] and [NP][64 d][64 B]; slot keys: a ds_read_b128 lane group
 // holds every key parity twice per value of (key >> 1) & 7, and every 64-byte quadrant once per value of (row >> 2) & 3
 constexpr int XK_PLANE = 32 * 128, XV_PLANE = 64 * 64;
 __device__ __forceinline__ int xk_swz(int key) { return (key >> 1) & 7; }

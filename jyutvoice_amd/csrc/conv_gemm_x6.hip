@@ -1,4 +1,5 @@
-// conv_gemm with the contraction on the bf16 matrix cores at fp32 accuracy ("bf16x6").
+// conv_gemm with the contraction on the 16-bit matrix cores at fp32 accuracy: "bf16x6" (NP = 3, below) for any fp32
+// operand, "fp16x3" (NP = 2, see the kernel's template comment and DESIGN.md 5) where the caller has proven the range.
 //
 // Every fp32 operand is split into three bf16 planes x = h + m + l (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m):
 // 24 significant bits) and the product is formed from the six partial products whose weight is >= 2^-16:
