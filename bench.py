@@ -225,7 +225,10 @@ def main():
             "config": {"workload": ("C3: text encoder -> CFM flow decoder (Euler+CFG) -> HiFT vocoder, full synthesise()+inference()"
                                     if args.workload == "c3" else "C2: CFM flow decoder loop alone (Euler+CFG), N(0,1) mu, full mask"),
                        "utterances_per_gpu": B, "global_batch": B * world, "tokens": Tt, "mel_frames": T,
-                       "audio_seconds_per_utterance": T * 0.02, "n_timesteps": n_steps, "parallelism": f"utterance-dp{world}"},
+                       "audio_seconds_per_utterance": T * 0.02, "n_timesteps": n_steps, "parallelism": f"utterance-dp{world}",
+                       "contraction": ("bf16x6 everywhere (JV_EXACT_RANGE)" if os.environ.get("JV_EXACT_RANGE") else
+                                       "fp32-accurate split-plane MFMA: fp16x3 on the estimator's range-proven linears and "
+                                       "attention, bf16x6 elsewhere (DESIGN.md 5; JV_EXACT_RANGE=1 forces bf16x6)")},
         }
         if kern:
             tot_ms = sum(v["ms"] for v in kern.values())
