@@ -362,6 +362,7 @@ int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
     // plain tile plus this 10 us pass -- and cannot double-buffer its 256-row weight tile within two workgroups per CU.)
     if (nbatch != 1 || a.res2 || a.accumulate || a.ldo != a.N || (a.N & 3) || a.N > 1024)
       return fail(JV_ERR_ARG, "conv_gemm: LayerNorm epilogue needs a contiguous [M,N] output, N % 4 == 0, N <= 1024");
+    if (a.amax_out) return fail(JV_ERR_ARG, "conv_gemm: amax_out is not tracked through the LayerNorm epilogue");
     ConvGemmArgs g = a;
     g.ln = 0; g.act = ACT_NONE; g.rowmask_out = nullptr; g.rowvec = nullptr; g.res1 = nullptr; g.out_scale = 1.f;
     JV_TRY(conv_gemm(g, 1, st));

@@ -30,7 +30,8 @@ __device__ __forceinline__ void epilogue_passes(F& f) {      // f(0), f(1), ... 
 template <int WM, int WN, int EPI, bool SC = false>
 __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out, f32x16 (&acc)[WM / 32][WN / 32], float* smem,
                                               const int m0, const int n0, const int wm, const int wn,
-                                              unsigned long long t_start, unsigned long long t_loop) {
+                                              unsigned long long t_start, unsigned long long t_loop,
+                                              const float a_scale = 1.f) {
   constexpr int MT = WM / 32, NT = WN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, half = lane >> 5;
@@ -58,10 +59,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
   }
   f32x4 cs = {1.f, 1.f, 1.f, 1.f};
   if constexpr (SC) {
-    const float inv = 1.0f / p.a_scale;      // powers of two: exact
+    const float inv = 1.0f / a_scale;        // powers of two: exact
 #pragma unroll
     for (int e = 0; e < 4; ++e) cs[e] = (n + e < p.N) ? p.colscale[n + e] * inv : 0.f;
   }
+  // p.amax_out: max |value| over everything this thread stores, kept as the bit pattern of the non-negative float --
+  // unsigned order is numeric order there, with inf and NaN on top, so the integer max propagates them
+  unsigned amax = 0u;
+  auto track = [&](const f32x4& t) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) amax = max(amax, __float_as_uint(t[e]) & 0x7fffffffu);
+  };
   auto pass = [&](auto mt_tag) {
     constexpr int mt = decltype(mt_tag)::value;
     // The slab is private to the wave and LDS executes one wave's accesses in program order: no barrier between a
@@ -104,7 +112,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
             *reinterpret_cast<u32x2_*>(o2 + p.out2_plane) = u32x2_{s0.l, s1.l};
           }
         } else
-        if (nin && mrow + it * RPI < p.M && !JV_ABLATE(p, 64)) *reinterpret_cast<f32x4*>(ob + (long)(it * RPI) * p.ldo) = t;
+        if (nin && mrow + it * RPI < p.M && !JV_ABLATE(p, 64)) {
+          *reinterpret_cast<f32x4*>(ob + (long)(it * RPI) * p.ldo) = t;
+          if (p.amax_out) track(t);
+        }
       }
       return;
     }
@@ -159,6 +170,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
           res[e] = t * p.out_scale + pv[u][e];
         }
         float* o = out + (long)m * p.ldo + n;
+        if (p.amax_out) {
+          f32x4 tr = res;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e >= p.N) tr[e] = 0.f;
+          track(tr);
+        }
         if (vec) {
           if (!JV_ABLATE(p, 64) || res[0] == 12345.678f) *reinterpret_cast<f32x4*>(o) = res;
         } else {
@@ -169,6 +187,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
     }
   };
   epilogue_passes<0, MT>(pass);
+  if (p.amax_out) {      // one atomic per wave; non-negative floats order like their bit patterns, NaN above everything
+    unsigned u = amax;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o));
+    // The slot only grows, so a (possibly stale) read that is already >= u makes the atomic unnecessary: after the first
+    // few workgroups almost none is issued (18 K workgroups x 4 waves hammering one address cost 0.5 ms per launch).
+    if (lane == 0 && u > *reinterpret_cast<volatile const unsigned*>(p.amax_out))
+      atomicMax(reinterpret_cast<unsigned*>(p.amax_out), u);
+  }
   if (JV_STAMP(p)) t_p0 = __builtin_amdgcn_s_memtime();
   if (JV_STAMP(p) && tid == 0) {
     unsigned long long* d = p.stamps + (size_t)blockIdx.x * 4;

@@ -67,7 +67,8 @@ template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int NWB, in
 __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EPI != 4) ? 5 : 2) void conv_gemm_x6_kernel(const ConvGemmArgs p, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = WM / 32, NT = WN / 32;
-  static_assert(NP == 3 || (NP == 2 && PRO == PRO_NONE), "fp16x3 takes plain operands only");
+  // fp16x3 scale of A: the caller's (proven at load time) or derived here from the measured maximum of the buffer
+  const float a_scale = NP == 2 ? (p.amax_in ? h3_scale_dev(*p.amax_in + p.a_extra) : p.a_scale) : 1.f;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
   static_assert(NWB == 1 || NWB == 2, "one or two weight buffers");
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
   constexpr bool AQ = NA2 == 0;                  // quarter-row staging
   constexpr bool APL = NA2 == 3;                 // A arrives as fp16 planes (p.A2) by LDS-DMA, double-buffered like W
   static_assert(!APL || (NP == 2 && NWB == 2 && PRO == PRO_NONE), "pre-split A: fp16x3, two buffers, plain prologue");
+  static_assert(NP == 2 || NP == 3, "two fp16 or three bf16 planes");
   constexpr int NR = (AQ || APL) ? 1 : NA2, NG = AQ ? 1 : 2;
   const int arow = AQ ? tid >> 2 : tid >> 1, kpart = AQ ? tid & 3 : tid & 1;
   const int koff = (AQ ? 8 : 16) * kpart;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
             u32x4 h, l;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const Split2 t = split2h_pair(x[2 * e] * p.a_scale, x[2 * e + 1] * p.a_scale);
+              const Split2 t = split2h_pair(x[2 * e] * a_scale, x[2 * e + 1] * a_scale);
               h[e] = t.h;
               l[e] = t.l;
             }
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
     c = c2;
   }
   __syncthreads();
-  conv_epilogue<WM, WN, EPI, NP == 2>(p, out, acc, smem, m0, n0, wm, wn, t_start, t_loop);
+  conv_epilogue<WM, WN, EPI, NP == 2>(p, out, acc, smem, m0, n0, wm, wn, t_start, t_loop, a_scale);
 }
 
 namespace {
@@ -379,9 +381,7 @@ int x6_launch4(const ConvGemmArgs& a, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int NWB>
 int x6_launch3(const ConvGemmArgs& a, hipStream_t st) {
-  if constexpr (PRO == PRO_NONE) {
-    if (a.W2) return x6_launch4<BM, BN, WM, WN, PRO, EPI, NA2, NWB, 2>(a, st);
-  }
+  if (a.W2) return x6_launch4<BM, BN, WM, WN, PRO, EPI, NA2, NWB, 2>(a, st);
   return x6_launch4<BM, BN, WM, WN, PRO, EPI, NA2, NWB, 3>(a, st);
 }
 
@@ -436,8 +436,8 @@ int x6_launch(const ConvGemmArgs& a, hipStream_t st) {
 // Same contract as conv_gemm() (argument checks done there); requires a.W3, or a.W2 + a.colscale (fp16x3, plain prologue).
 int conv_gemm_x6(const ConvGemmArgs& a0, hipStream_t st) {
   ConvGemmArgs a = a0;
-  if (a.W2 && (a.pro != PRO_NONE || !a.colscale || !(a.a_scale > 0.f))) {
-    if (!a.W3) return fail(JV_ERR_ARG, "conv_gemm_x6: fp16x3 needs a plain prologue, colscale and a_scale");
+  if (a.W2 && (!a.colscale || !(a.amax_in || a.a_scale > 0.f))) {
+    if (!a.W3) return fail(JV_ERR_ARG, "conv_gemm_x6: fp16x3 needs colscale and a_scale or amax_in");
     a.W2 = nullptr;
   }
   if (!a.W2 && !a.W3) return fail(JV_ERR_ARG, "conv_gemm_x6: no weight planes");

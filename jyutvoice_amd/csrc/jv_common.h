@@ -91,6 +91,15 @@ struct ConvGemmArgs {
   long w2_plane;
   const float* colscale;
   float a_scale;
+  // ... or MEASURED: amax_in points at a device float >= max |A| over every row this launch may read, maintained by the
+  // kernels that wrote A (amax_out below); the kernel then derives its own power of two from *amax_in + a_extra, where
+  // a_extra bounds what the prologue can add (Snake: x + sin^2(alpha x) / alpha <= |x| + 1 / min alpha).  Overflow is
+  // impossible by construction either way; a_scale is ignored when amax_in is set.
+  const float* amax_in;
+  float a_extra;
+  // optional: atomic max of |value| over everything this launch writes (bit pattern of a non-negative float), for the
+  // consumer's amax_in.  The slot must be zeroed by the caller before the first producer of the buffer runs.
+  float* amax_out;
   // optional with W2 (linears, ntaps = 1): A already split by its producer -- two fp16 planes [2][a_rows][lda2] of
   // A * a_scale (LayerNorm, attention and the GELU epilogue write them, same bytes as the fp32 rows); both operands then
   // reach LDS by LDS-DMA and the main loop has no VALU work and one barrier per step

@@ -74,6 +74,12 @@ __device__ __forceinline__ Split3 split3_pair(const float x0, const float x1) {
 // of two chosen from a proven bound.
 typedef _Float16 jv_f16x2 __attribute__((ext_vector_type(2)));
 struct Split2 { unsigned h, l; };
+// largest power of two s with bound * s <= 60000 (the host's h3_scale_for_bound, registry.hip), for a bound measured on
+// the device: the exponent of 60000 / bound with the mantissa cleared; NaN / inf bounds give NaN / 0 and so propagate
+__device__ __forceinline__ float h3_scale_dev(const float bound) {
+  const float q = 60000.f / fmaxf(bound, 1e-30f);
+  return fminf(__uint_as_float(__float_as_uint(q) & 0xff800000u), 16777216.f);
+}
 __device__ __forceinline__ Split2 split2h_pair(const float x0, const float x1) {
   const jv_f32x2 x = {x0, x1};
   const jv_f16x2 h = __builtin_convertvector(x, jv_f16x2);

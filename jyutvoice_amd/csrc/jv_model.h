@@ -82,7 +82,13 @@ struct EncoderW {
   GemmW spk_affine;
 };
 
-struct ResBlockW { GemmW c1[3], c2[3]; const float* a1[3]; const float* a2[3]; int k = 0; };
+struct ResBlockW {
+  GemmW c1[3], c2[3];
+  const float* a1[3];
+  const float* a2[3];
+  float e1[3] = {}, e2[3] = {};   // max_c 1 / (alpha_c + 1e-9): what Snake can add to |x| (fp16x3 with a measured bound); 0 = n/a
+  int k = 0;
+};
 struct HiftW {
   GemmW f0_conv[5];
   const float *f0_cls_w = nullptr, *f0_cls_b = nullptr;

@@ -395,9 +395,26 @@ struct Packer {
     }
     return m;
   }
+  // x + sin^2(alpha x) / (alpha + 1e-9) <= |x| + 1 / (alpha + 1e-9): the largest such term over the channels, 0 when some
+  // alpha is not positive (then the layer stays on bf16x6)
+  float snake_extra(const float* alpha_dev, int n) {
+    if (!alpha_dev || rc != JV_OK) return 0.f;
+    std::vector<float> h((size_t)n);
+    if (hipMemcpyAsync(h.data(), alpha_dev, h.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+      rc = fail(JV_ERR_HIP, "alpha readback failed");
+      return 0.f;
+    }
+    float m = 0.f;
+    for (float a : h) {
+      if (!(a > 1e-6f) || !(a < 1e30f)) return 0.f;
+      m = fmaxf(m, 1.0f / (a + 1e-9f));
+    }
+    return m;
+  }
   // attach the fp16x3 planes; returns the device vector of the rows' L1 norms (for the bound of what the layer produces)
   const float* half3(GemmW& g) {
-    if (!g.w || rc != JV_OK || g.ntaps != 1) return nullptr;
+    if (!g.w || rc != JV_OK) return nullptr;
     const long n = (long)g.n_rows * g.ldw;
     float* d = alloc((size_t)n + 8);             // 2 planes x 2 bytes
     float* cs = alloc((size_t)g.n_rows);
@@ -654,6 +671,7 @@ int finalize_model(Context& c, int model, hipStream_t st) {
     const int up_k[3] = {16, 11, 7}, up_s[3] = {8, 5, 3}, sd_k[3] = {30, 6, 1}, src_k[3] = {7, 7, 11}, rb_k[3] = {3, 7, 11};
     for (int i = 0; i < 3; ++i) {
       h.ups[i] = pk.convT_wn("ups." + S(i) + ".", HIFT_CH >> i, HIFT_CH >> (i + 1), up_k[i], up_s[i]);
+      (void)pk.half3(h.ups[i]);
       // strided source conv as a GEMM over k*32 contiguous floats of the 32-column s_stft row buffer
       GemmW sd = pk.conv_named("source_downs." + S(i) + ".", HIFT_CH >> (i + 1), HIFT_NFFT + 2, sd_k[i], 32);
       sd.Cin = sd_k[i] * 32;
@@ -668,6 +686,11 @@ int finalize_model(Context& c, int model, hipStream_t st) {
         w.c2[j] = pk.conv_wn(q + "convs2." + S(j) + ".", ch, ch, k);
         w.a1[j] = pk.ptr(q + "activations1." + S(j) + ".alpha");
         w.a2[j] = pk.ptr(q + "activations2." + S(j) + ".alpha");
+        // fp16x3 with a measured input bound (hift.hip): planes + what the Snake prologue can add on top of |x|
+        (void)pk.half3(w.c1[j]);
+        (void)pk.half3(w.c2[j]);
+        w.e1[j] = pk.snake_extra(w.a1[j], ch);
+        w.e2[j] = pk.snake_extra(w.a2[j], ch);
       }
       return w;
     };
