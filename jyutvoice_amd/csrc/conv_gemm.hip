@@ -362,12 +362,12 @@ int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
     // plain tile plus this 10 us pass -- and cannot double-buffer its 256-row weight tile within two workgroups per CU.)
     if (nbatch != 1 || a.res2 || a.accumulate || a.ldo != a.N || (a.N & 3) || a.N > 1024)
       return fail(JV_ERR_ARG, "conv_gemm: LayerNorm epilogue needs a contiguous [M,N] output, N % 4 == 0, N <= 1024");
-    if (a.amax_out) return fail(JV_ERR_ARG, "conv_gemm: amax_out is not tracked through the LayerNorm epilogue");
     ConvGemmArgs g = a;
     g.ln = 0; g.act = ACT_NONE; g.rowmask_out = nullptr; g.rowvec = nullptr; g.res1 = nullptr; g.out_scale = 1.f;
+    g.amax_out = nullptr;      // what stays in `out` is what the LayerNorm pass writes
     JV_TRY(conv_gemm(g, 1, st));
     return ln_epilogue_rows(a.out, a.ln_g, a.ln_b, a.ln_eps, a.M, a.N, a.act, a.rowmask_out, a.rowvec, a.row_sample,
-                            a.rowvec_ld, a.res1, a.ldr1, a.out_scale, st);
+                            a.rowvec_ld, a.res1, a.ldr1, a.out_scale, st, a.amax_out);
   }
   if (const char* ab = tuning_env("JV_ABLATE")) const_cast<ConvGemmArgs&>(a).ablate = atoi(ab);
   if ((a.W3 || a.W2) && nbatch == 1 && (a.ldw & 7) == 0 && !dyn_env("JV_NO_X6")) return conv_gemm_x6(a, st);

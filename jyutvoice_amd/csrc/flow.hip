@@ -24,6 +24,10 @@ struct FlowWs {
   float *xin = nullptr;                                               // [rows,320]
   float *h = nullptr, *h2 = nullptr, *res = nullptr, *cat = nullptr;  // [rows,256] x3, [rows,512]
   float *ln = nullptr, *qkv = nullptr, *att = nullptr, *ff = nullptr; // 256, 1536, 512, 1024
+  // max |value| written to the trunk buffers (h, h2, cat) during the current estimator call: every kernel that writes one
+  // of them tracks it (ConvGemmArgs::amax_out, ln_epilogue_rows), and the convolutions that read them -- whose input, the
+  // residual stream, has no load-time bound -- derive their fp16x3 scale from it (amax_in).  Zeroed at the start of a call.
+  float* amax = nullptr;
   float *d = nullptr;                                                 // [rows,80]
   float *tsin = nullptr, *t1 = nullptr, *tmish = nullptr, *temb = nullptr;
   float *t_dev = nullptr, *t_table = nullptr, *dt_table = nullptr;
@@ -70,6 +74,7 @@ int flow_ws_create(Context& c) {
   JV_TRY(F(&w->t1, (size_t)B2 * 1024));
   JV_TRY(F(&w->tmish, (size_t)B2 * 1024));
   JV_TRY(F(&w->temb, (size_t)B2 * EST_NRES * 256));
+  JV_TRY(F(&w->amax, 4));
   JV_TRY(F(&w->t_dev, (size_t)B2));
   JV_TRY(F(&w->t_table, (size_t)w->max_steps));
   JV_TRY(F(&w->dt_table, (size_t)w->max_steps));
@@ -154,6 +159,12 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.tap_row0 = -2;
     a.rowmask_in = w.rowmask;
   };
+  // trunk convolutions: fp16x3 from the measured bound of the trunk buffers (not for A = xin, which assemble_xin writes)
+  JV_HIP(hipMemsetAsync(w.amax, 0, sizeof(float), st));
+  auto h3m = [&](ConvGemmArgs& a, const GemmW& m) {
+    if (c.exact_range || !m.w2 || a.A == w.xin) return;
+    a.W2 = m.w2; a.w2_plane = (long)m.n_rows * m.ldw; a.colscale = m.colscale; a.amax_in = w.amax; a.a_extra = 0.f;
+  };
   // CausalResnetBlock1D (decoder.py:110-115, 784-795)
   auto resnet = [&](int i, const float* in, int ldin, float* out, int ldo) -> int {
     const ResnetW& r = e.res[i];
@@ -162,15 +173,20 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.ln = 1; a.ln_g = r.ln1.g; a.ln_b = r.ln1.b; a.ln_eps = 1e-5f; a.act = ACT_MISH;
     a.rowmask_out = w.rowmask;
     a.rowvec = w.temb + i * 256; a.row_sample = w.row_sample; a.rowvec_ld = EST_NRES * 256;
+    h3m(a, r.block1);
+    a.amax_out = w.amax;      // -> h2
     JV_TRY(conv_gemm(a, 1, st));
     a = base_args(g, in, ldin, r.res, w.res, 256);
     a.rowmask_in = w.rowmask;
+    h3m(a, r.res);
     JV_TRY(conv_gemm(a, 1, st));
     a = base_args(g, w.h2, 256, r.block2, out, ldo);
     causal3(a);
     a.ln = 1; a.ln_g = r.ln2.g; a.ln_b = r.ln2.b; a.ln_eps = 1e-5f; a.act = ACT_MISH;
     a.rowmask_out = w.rowmask;
     a.res1 = w.res; a.ldr1 = 256;
+    h3m(a, r.block2);
+    a.amax_out = w.amax;      // -> h
     return conv_gemm(a, 1, st);
   };
   // BasicTransformerBlock (transformer.py:355-443): h -> h, last GEMM may retarget its output
@@ -204,6 +220,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     JV_TRY(attention64(at, st));
     a = base_args(g, w.att, 512, b.out, h, 256);
     a.res1 = h; a.ldr1 = 256;
+    a.amax_out = w.amax;      // -> h
     h3(a, b.out);
     if (pre(b.out)) planes_in(a, w.att, 512);
     JV_TRY(conv_gemm(a, 1, st));
@@ -219,6 +236,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     JV_TRY(conv_gemm(a, 1, st));
     a = base_args(g, w.ff, 1024, b.ff2, out, ldo);
     a.res1 = h; a.ldr1 = 256;
+    a.amax_out = w.amax;      // -> h / cat
     h3(a, b.ff2);
     if (ff_planes) planes_in(a, w.ff, 1024);
     return conv_gemm(a, 1, st);
@@ -231,6 +249,8 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   {
     ConvGemmArgs a = base_args(g, skip, 512, e.down_conv, w.h, 256);
     causal3(a);
+    h3m(a, e.down_conv);
+    a.amax_out = w.amax;
     JV_TRY(conv_gemm(a, 1, st));
   }
   // mid x12; the last block writes straight into columns [0,256) of the concat buffer
@@ -247,15 +267,20 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   {
     ConvGemmArgs a = base_args(g, w.h, 256, e.up_conv, w.h2, 256);
     causal3(a);
+    h3m(a, e.up_conv);
+    a.amax_out = w.amax;
     JV_TRY(conv_gemm(a, 1, st));
     a = base_args(g, w.h2, 256, e.final_conv, w.h, 256);
     causal3(a);
     a.ln = 1; a.ln_g = e.final_ln.g; a.ln_b = e.final_ln.b; a.ln_eps = 1e-5f; a.act = ACT_MISH;
     a.rowmask_out = w.rowmask;
+    h3m(a, e.final_conv);
+    a.amax_out = w.amax;
     JV_TRY(conv_gemm(a, 1, st));
     a = base_args(g, w.h, 256, e.final_proj, w.d, 80);
     a.rowmask_in = w.rowmask;
     a.rowmask_out = w.rowmask;
+    h3m(a, e.final_proj);
     JV_TRY(conv_gemm(a, 1, st));
   }
   return JV_OK;

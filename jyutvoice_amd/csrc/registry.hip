@@ -579,6 +579,10 @@ int finalize_model(Context& c, int model, hipStream_t st) {
       e.res[i].block2 = pk.conv_named(q + "block2.block.0.", EST_CH, EST_CH, 3);
       e.res[i].ln2 = pk.ln(q + "block2.block.2.", "weight", "bias");
       e.res[i].res = pk.linear(q + "res_conv.weight", q + "res_conv.bias", EST_CH, cin);
+      // fp16x3 with the measured bound of the residual stream (flow.hip)
+      (void)pk.half3(e.res[i].block1);
+      (void)pk.half3(e.res[i].block2);
+      (void)pk.half3(e.res[i].res);
       for (int j = 0; j < EST_NBLK; ++j) {
         const std::string b = stage[i] + "1." + S(j) + ".";
         BtbW& w = e.blk[i][j];
@@ -623,6 +627,10 @@ int finalize_model(Context& c, int model, hipStream_t st) {
     e.final_conv = pk.conv_named(p + "final_block.block.0.", EST_CH, EST_CH, 3);
     e.final_ln = pk.ln(p + "final_block.block.2.", "weight", "bias");
     e.final_proj = pk.linear(p + "final_proj.weight", p + "final_proj.bias", N_FEATS, EST_CH);
+    (void)pk.half3(e.down_conv);
+    (void)pk.half3(e.up_conv);
+    (void)pk.half3(e.final_conv);
+    (void)pk.half3(e.final_proj);
 
     // ---------------- text encoder + duration predictor ----------------
     EncoderW& n = c.enc;

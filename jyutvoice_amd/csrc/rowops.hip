@@ -143,13 +143,15 @@ __global__ __launch_bounds__(256) void ln_epilogue_kernel(float* __restrict__ x,
                                                           const float* __restrict__ b, float eps, long rows, int C, int act,
                                                           const unsigned char* __restrict__ rowmask,
                                                           const float* __restrict__ rowvec, const int* __restrict__ row_sample,
-                                                          int rowvec_ld, const float* __restrict__ res, long ldr, float scale) {
+                                                          int rowvec_ld, const float* __restrict__ res, long ldr, float scale,
+                                                          float* __restrict__ amax_out) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int c4n = C >> 2;
   f32x4 v[VPL];
   float sum = 0.f;
+  unsigned amax = 0u;      // max |value written|, as conv_gemm's epilogue tracks it (ConvGemmArgs::amax_out)
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int c4 = lane + 64 * i;
@@ -185,14 +187,23 @@ __global__ __launch_bounds__(256) void ln_epilogue_kernel(float* __restrict__ x,
       for (int e = 0; e < 4; ++e) r[e] = keep ? act_apply(r[e], act) : 0.f;
       if (rv) r += *reinterpret_cast<const f32x4*>(rv + 4 * c4);
       if (res) r += *reinterpret_cast<const f32x4*>(res + row * ldr + 4 * c4);
-      *reinterpret_cast<f32x4*>(x + row * C + 4 * c4) = r * scale;
+      r = r * scale;
+      *reinterpret_cast<f32x4*>(x + row * C + 4 * c4) = r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) amax = max(amax, __float_as_uint(r[e]) & 0x7fffffffu);
     }
+  }
+  if (amax_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o));
+    if (lane == 0 && amax > *reinterpret_cast<volatile const unsigned*>(amax_out))
+      atomicMax(reinterpret_cast<unsigned*>(amax_out), amax);
   }
 }
 
 int ln_epilogue_rows(float* x, const float* g, const float* b, float eps, long rows, int C, int act,
                      const unsigned char* rowmask, const float* rowvec, const int* row_sample, int rowvec_ld, const float* res,
-                     long ldr, float scale, hipStream_t st) {
+                     long ldr, float scale, hipStream_t st, float* amax_out) {
   if (rows <= 0) return JV_OK;
   if ((C & 3) || C > 1024 || (rowvec && (rowvec_ld & 3)) || (res && (ldr & 3)))
     return fail(JV_ERR_ARG, "ln_epilogue_rows: C, rowvec_ld and ldr must be multiples of 4 (C <= 1024)");
@@ -201,10 +212,10 @@ int ln_epilogue_rows(float* x, const float* g, const float* b, float eps, long r
   if (prof) prof_begin(st);
   if (C <= 256)
     hipLaunchKernelGGL((ln_epilogue_kernel<1>), grid, dim3(256), 0, st, x, g, b, eps, rows, C, act, rowmask, rowvec, row_sample,
-                       rowvec_ld, res, ldr, scale);
+                       rowvec_ld, res, ldr, scale, amax_out);
   else
     hipLaunchKernelGGL((ln_epilogue_kernel<4>), grid, dim3(256), 0, st, x, g, b, eps, rows, C, act, rowmask, rowvec, row_sample,
-                       rowvec_ld, res, ldr, scale);
+                       rowvec_ld, res, ldr, scale, amax_out);
   if (prof) prof_end(st, "ln_epilogue", 0.0, 4.0 * rows * C * (res ? 3 : 2));
   JV_HIP(hipGetLastError());
   return JV_OK;
