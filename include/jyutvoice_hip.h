@@ -154,11 +154,18 @@ int jv_hift_decode(jv_context* ctx, const float* mel, const float* s, const int3
  *                  W [N, K], a_bound = the caller's bound on |A| (the kernel's contract: |A| <= a_bound); presplit = 1:
  *                  A is first written as fp16 planes (what LayerNorm / attention / the GELU epilogue do in the estimator)
  *                  and both operands travel by LDS-DMA; 2: reuse the previous call's planes (timing only).
- * jv_op_attention_h3: jv_op_attention through the fp16x3 kernel, with the caller's bounds on |q|, |k|, |v|. */
+ * jv_op_attention_h3: jv_op_attention through the fp16x3 kernel, with the caller's bounds on |q|, |k|, |v|.
+ * jv_op_conv_h3_measured: jv_op_conv_gemm through the fp16x3 main loop with a bound measured on the device: amax_in points
+ *                  at a float >= max |A| (the amax_out of A's producer), a_extra bounds what the prologue adds; amax_out
+ *                  (optional, zero it first) receives max |out|.  amax_in = NULL: bf16x6, tracking only. */
 int jv_op_conv_gemm(const float* A, int64_t a_rows, int M, int Cin, int ntaps, int tap_row0, int dil, const float* W, int N,
                     const float* bias, int act, int prologue, const float* alpha, float slope, const float* ln_g,
                     const float* ln_b, float ln_eps, const uint8_t* rowmask, const float* res, float* out, void* stream);
 int jv_op_attention(const float* qkv, const int32_t* lens, int B, int G, int S, int L, float* out, void* stream);
+int jv_op_conv_h3_measured(const float* A, int64_t a_rows, int M, int Cin, int ntaps, int tap_row0, int dil, const float* W,
+                           int N, const float* bias, int act, int prologue, const float* alpha, float slope,
+                           const uint8_t* rowmask, const float* res, const float* amax_in, float a_extra, float* amax_out,
+                           float* out, void* stream);
 int jv_op_attention_h3(const float* qkv, const int32_t* lens, int B, int G, int S, int L, float q_bound, float k_bound,
                        float v_bound, float* out, void* stream);
 int jv_op_linear_h3(const float* A, int64_t rows, int M, int K, const float* W, int N, const float* bias, int act,

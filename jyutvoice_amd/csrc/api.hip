@@ -294,6 +294,48 @@ int jv_op_attention(const float* qkv, const int32_t* lens, int B, int G, int S, 
   return jv::attention64(at, static_cast<hipStream_t>(stream));
 }
 
+// conv_gemm through the fp16x3 main loop with a MEASURED bound: amax_in = device float >= max |A| (e.g. the amax_out of
+// the launch that produced A), a_extra = what the prologue can add; amax_out (optional) receives max |out| (test hook)
+int jv_op_conv_h3_measured(const float* A, int64_t a_rows, int M, int Cin, int ntaps, int tap_row0, int dil, const float* W,
+                           int N, const float* bias, int act, int prologue, const float* alpha, float slope,
+                           const uint8_t* rowmask, const float* res, const float* amax_in, float a_extra, float* amax_out,
+                           float* out, void* stream) {
+  static bool inited = false;
+  if (!inited) {
+    JV_TRY(jv::conv_gemm_init());
+    inited = true;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t n = (size_t)N * ntaps * Cin;
+  static void* scratch = nullptr;
+  static size_t cap = 0;
+  const size_t need = n * 10 + (size_t)N * 12 + 512;      // 2 fp16 + 3 bf16 planes, colscale, row stats
+  if (need > cap) {
+    if (scratch) (void)hipFree(scratch);
+    JV_HIP(hipMalloc(&scratch, need));
+    cap = need;
+  }
+  unsigned short* planes2 = static_cast<unsigned short*>(scratch);
+  unsigned short* planes3 = planes2 + 2 * n;
+  float* cs = reinterpret_cast<float*>(static_cast<char*>(scratch) + ((n * 10 + 63) & ~(size_t)63));
+  jv::ConvGemmArgs a;
+  jv::conv_gemm_defaults(a);
+  a.A = A; a.lda = Cin; a.a_rows = a_rows; a.M = M; a.Cin = Cin; a.ntaps = ntaps; a.tap_row0 = tap_row0; a.tap_dil = dil;
+  a.W = W; a.ldw = ntaps * Cin; a.n_rows_w = N; a.N = N; a.bias = bias; a.out = out; a.ldo = N;
+  a.act = act; a.pro = prologue; a.pro_alpha = alpha; a.pro_slope = slope;
+  a.rowmask_in = rowmask; a.rowmask_out = rowmask;
+  a.res1 = res; a.ldr1 = N;
+  a.amax_out = amax_out;
+  if (amax_in) {
+    JV_TRY(jv::split2h_planes(W, N, ntaps * Cin, cs + N, planes2, cs, st));
+    a.W2 = planes2; a.w2_plane = (long)n; a.colscale = cs; a.amax_in = amax_in; a.a_extra = a_extra;
+  } else {      // producer only: bf16x6
+    JV_TRY(jv::split3_planes(W, planes3, (long)n, st));
+    a.W3 = planes3; a.w3_plane = (long)n;
+  }
+  return jv::conv_gemm(a, 1, st);
+}
+
 // the fp16x3 attention kernel; q_bound, k_bound, v_bound: the caller's proven bounds on |q|, |k|, |v| (test hook)
 int jv_op_attention_h3(const float* qkv, const int32_t* lens, int B, int G, int S, int L, float q_bound, float k_bound,
                        float v_bound, float* out, void* stream) {

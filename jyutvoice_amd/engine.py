@@ -250,6 +250,21 @@ def op_attention(qkv, lens, B, G, S, L):
     return out
 
 
+def op_conv_h3_measured(A, W, bias=None, ntaps=1, tap_row0=0, dil=1, M=None, act="none", prologue="none", alpha=None,
+                        slope=0.0, rowmask=None, res=None, amax_in=None, a_extra=0.0, amax_out=None):
+    """conv_gemm with the fp16x3 scale derived on the device from amax_in (a 1-element cuda tensor >= max |A|) + a_extra;
+    amax_out (1-element cuda tensor, zeroed by the caller) receives max |out|.  amax_in=None: bf16x6, tracking only."""
+    lib = _lib.load()
+    rows, cin = A.shape
+    N = W.shape[0]
+    M = rows if M is None else M
+    out = torch.empty(M, N, device=A.device)
+    check(lib.jv_op_conv_h3_measured(_ptr(A), rows, M, cin, ntaps, tap_row0, dil, _ptr(W), N, _ptr(bias), _lib.ACT[act],
+                                     _lib.PRO[prologue], _ptr(alpha), float(slope), _ptr(rowmask), _ptr(res), _ptr(amax_in),
+                                     float(a_extra), _ptr(amax_out), _ptr(out), _stream(A.device)))
+    return out
+
+
 def op_attention_h3(qkv, lens, B, G, S, L, bounds=None):
     """fp16x3 attention kernel; bounds = (|q|, |k|, |v|) maxima the caller vouches for (default: measured)"""
     lib = _lib.load()

@@ -377,3 +377,62 @@ def test_h3_presplit_operand_is_bit_identical(dev, monkeypatch, tile):
     for i in range(30):
         noise.normal_()
         assert torch.equal(op_linear_h3(A, W, b, a_bound=8.0, presplit=1), first), i
+
+
+@pytest.mark.parametrize("k,dil,C,scale", [(11, 5, 64, 1.0), (7, 3, 128, 30.0), (3, 1, 256, 1e-3)])
+def test_h3_measured_bound_chain(dev, k, dil, C, scale):
+    """the vocoder's / trunk's form of fp16x3: a producing convolution tracks max |out| on the device (amax_out), the
+    consuming Snake convolution derives its scale from that slot + what Snake can add -- no host involvement, no overflow
+    possible at any input magnitude.  Checked: the tracked maximum is exact, and the consumer meets the tolerance of the
+    bf16x6 test above on the same problem, at three input scales"""
+    from jyutvoice_amd.engine import op_conv_h3_measured
+    g = torch.Generator().manual_seed(k * 100 + dil + 7)
+    rows = 700
+    X = torch.randn(rows, C, generator=g) * scale
+    w0 = torch.randn(C, C, 3, generator=g) / math.sqrt(3 * C)
+    w = torch.randn(C, C, k, generator=g) / math.sqrt(k * C)
+    b = torch.randn(C, generator=g) * 0.1 * scale
+    alpha = 1 + 0.1 * torch.randn(C, generator=g).abs()
+    res = torch.randn(rows, C, generator=g) * scale
+    pad = dil * (k - 1) // 2
+    slot = torch.zeros(1, device=dev)
+    # producer (bf16x6, tracking only): A = conv3(X)
+    A = op_conv_h3_measured(X.to(dev), pack_conv(w0).to(dev), None, ntaps=3, tap_row0=-1, amax_out=slot)
+    assert float(slot) == float(A.abs().max())
+    # consumer: snake -> dilated conv -> + residual, scale from the slot
+    extra = float((1.0 / (alpha + 1e-9)).max())
+    slot2 = torch.zeros(1, device=dev)
+    out = op_conv_h3_measured(A, pack_conv(w).to(dev), b.to(dev), ntaps=k, tap_row0=-pad, dil=dil, prologue="snake",
+                              alpha=alpha.to(dev), res=res.to(dev), amax_in=slot, a_extra=extra, amax_out=slot2)
+    Ad = A.double().cpu()
+    sn = Ad + (1.0 / (alpha.double() + 1e-9)) * torch.sin(Ad * alpha.double()) ** 2
+    want = conv_rows_ref(sn, w, b, -pad, dil) + res.double()
+    assert torch.isfinite(out).all()
+    assert float((out.double().cpu() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+    assert float(slot2) == float(out.abs().max())
+    # leaky-relu consumer (the up-sampling convolutions): |lrelu(x)| <= |x|, nothing added
+    out = op_conv_h3_measured(A, pack_conv(w).to(dev), None, ntaps=k, tap_row0=-pad, dil=dil, prologue="lrelu", slope=0.1,
+                              amax_in=slot, a_extra=0.0)
+    want = conv_rows_ref(F.leaky_relu(Ad, 0.1), w, None, -pad, dil)
+    assert float((out.double().cpu() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_h3_measured_bound_extremes(dev):
+    """a tensor with one huge element (5e4 beside O(1) values) and an all-zero tensor: finite, correct"""
+    from jyutvoice_amd.engine import op_conv_h3_measured
+    g = torch.Generator().manual_seed(3)
+    M, K, N = 256, 256, 128
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    A = torch.randn(M, K, generator=g)
+    A[17, 5] = 5.0e4
+    slot = torch.tensor([float(A.abs().max())], device=dev)
+    out = op_conv_h3_measured(A.to(dev), W, None, amax_in=slot)
+    want = A.double() @ W.double().cpu().T
+    assert torch.isfinite(out).all()
+    err = (out.double().cpu() - want).abs()
+    assert float(err.max()) < 2e-6 * float(want.abs().max())
+    # rows without the outlier: the scale chosen for 5e4 leaves O(1) values an absolute error of ~1e-8 per element
+    assert float(err[torch.arange(M) != 17].max()) < 1e-5
+    Z = torch.zeros(M, K, device=dev)
+    out = op_conv_h3_measured(Z, W, None, amax_in=torch.zeros(1, device=dev))
+    assert float(out.abs().max()) == 0.0
