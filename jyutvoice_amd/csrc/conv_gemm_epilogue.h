@@ -66,6 +66,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
   // p.amax_out: max |value| over everything this thread stores, kept as the bit pattern of the non-negative float --
   // unsigned order is numeric order there, with inf and NaN on top, so the integer max propagates them
   unsigned amax = 0u;
+  // the slot's value when the epilogue starts (it only grows: a stale read is a valid lower bound), fetched before the
+  // slab work so that its latency is hidden
+  // (a plain, cacheable load on purpose: thousands of waves polling one L2 line with a volatile load serialise there)
+  const unsigned seen = p.amax_out ? *reinterpret_cast<const unsigned*>(p.amax_out) : 0xffffffffu;
   auto track = [&](const f32x4& t) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) amax = max(amax, __float_as_uint(t[e]) & 0x7fffffffu);
@@ -187,14 +191,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
     }
   };
   epilogue_passes<0, MT>(pass);
-  if (p.amax_out) {      // one atomic per wave; non-negative floats order like their bit patterns, NaN above everything
+  // one atomic per wave, and only from waves that saw something larger than the slot held (wave-uniform branch: once
+  // the slot is warm the reduction is skipped altogether)
+  if (p.amax_out && __builtin_amdgcn_ballot_w64(amax > seen) != 0) {
     unsigned u = amax;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o));
-    // The slot only grows, so a (possibly stale) read that is already >= u makes the atomic unnecessary: after the first
-    // few workgroups almost none is issued (18 K workgroups x 4 waves hammering one address cost 0.5 ms per launch).
-    if (lane == 0 && u > *reinterpret_cast<volatile const unsigned*>(p.amax_out))
-      atomicMax(reinterpret_cast<unsigned*>(p.amax_out), u);
+    // (18 K workgroups x 4 waves each sending an atomic to the one address cost 0.5 ms per launch before the check)
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(p.amax_out), u);
   }
   if (JV_STAMP(p)) t_p0 = __builtin_amdgcn_s_memtime();
   if (JV_STAMP(p) && tid == 0) {

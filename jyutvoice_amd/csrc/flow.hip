@@ -26,7 +26,7 @@ struct FlowWs {
   float *ln = nullptr, *qkv = nullptr, *att = nullptr, *ff = nullptr; // 256, 1536, 512, 1024
   // max |value| written to the trunk buffers (h, h2, cat) during the current estimator call: every kernel that writes one
   // of them tracks it (ConvGemmArgs::amax_out, ln_epilogue_rows), and the convolutions that read them -- whose input, the
-  // residual stream, has no load-time bound -- derive their fp16x3 scale from it (amax_in).  Zeroed at the start of a call.
+  // residual stream, has no load-time bound -- derive their fp16x3 scale from it (amax_in).  Zeroed once per solve.
   float* amax = nullptr;
   float *d = nullptr;                                                 // [rows,80]
   float *tsin = nullptr, *t1 = nullptr, *tmish = nullptr, *temb = nullptr;
@@ -160,7 +160,9 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.rowmask_in = w.rowmask;
   };
   // trunk convolutions: fp16x3 from the measured bound of the trunk buffers (not for A = xin, which assemble_xin writes)
-  JV_HIP(hipMemsetAsync(w.amax, 0, sizeof(float), st));
+  // (zeroed by the caller once per solve, not per call: in the first launch after a reset every wave sends its atomic --
+  // the per-CU L1 keeps serving the value the slot had at kernel start -- which cost 2.4 ms per step when done ten times)
+  float* const trunk_amax = c.exact_range ? nullptr : w.amax;      // nothing consumes it in exact-range mode
   auto h3m = [&](ConvGemmArgs& a, const GemmW& m) {
     if (c.exact_range || !m.w2 || a.A == w.xin) return;
     a.W2 = m.w2; a.w2_plane = (long)m.n_rows * m.ldw; a.colscale = m.colscale; a.amax_in = w.amax; a.a_extra = 0.f;
@@ -174,7 +176,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.rowmask_out = w.rowmask;
     a.rowvec = w.temb + i * 256; a.row_sample = w.row_sample; a.rowvec_ld = EST_NRES * 256;
     h3m(a, r.block1);
-    a.amax_out = w.amax;      // -> h2
+    a.amax_out = trunk_amax;      // -> h2
     JV_TRY(conv_gemm(a, 1, st));
     a = base_args(g, in, ldin, r.res, w.res, 256);
     a.rowmask_in = w.rowmask;
@@ -186,7 +188,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.rowmask_out = w.rowmask;
     a.res1 = w.res; a.ldr1 = 256;
     h3m(a, r.block2);
-    a.amax_out = w.amax;      // -> h
+    a.amax_out = trunk_amax;      // -> h
     return conv_gemm(a, 1, st);
   };
   // BasicTransformerBlock (transformer.py:355-443): h -> h, last GEMM may retarget its output
@@ -220,7 +222,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     JV_TRY(attention64(at, st));
     a = base_args(g, w.att, 512, b.out, h, 256);
     a.res1 = h; a.ldr1 = 256;
-    a.amax_out = w.amax;      // -> h
+    a.amax_out = trunk_amax;      // -> h
     h3(a, b.out);
     if (pre(b.out)) planes_in(a, w.att, 512);
     JV_TRY(conv_gemm(a, 1, st));
@@ -236,7 +238,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     JV_TRY(conv_gemm(a, 1, st));
     a = base_args(g, w.ff, 1024, b.ff2, out, ldo);
     a.res1 = h; a.ldr1 = 256;
-    a.amax_out = w.amax;      // -> h / cat
+    a.amax_out = trunk_amax;      // -> h / cat
     h3(a, b.ff2);
     if (ff_planes) planes_in(a, w.ff, 1024);
     return conv_gemm(a, 1, st);
@@ -250,7 +252,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     ConvGemmArgs a = base_args(g, skip, 512, e.down_conv, w.h, 256);
     causal3(a);
     h3m(a, e.down_conv);
-    a.amax_out = w.amax;
+    a.amax_out = trunk_amax;
     JV_TRY(conv_gemm(a, 1, st));
   }
   // mid x12; the last block writes straight into columns [0,256) of the concat buffer
@@ -268,14 +270,14 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     ConvGemmArgs a = base_args(g, w.h, 256, e.up_conv, w.h2, 256);
     causal3(a);
     h3m(a, e.up_conv);
-    a.amax_out = w.amax;
+    a.amax_out = trunk_amax;
     JV_TRY(conv_gemm(a, 1, st));
     a = base_args(g, w.h2, 256, e.final_conv, w.h, 256);
     causal3(a);
     a.ln = 1; a.ln_g = e.final_ln.g; a.ln_b = e.final_ln.b; a.ln_eps = 1e-5f; a.act = ACT_MISH;
     a.rowmask_out = w.rowmask;
     h3m(a, e.final_conv);
-    a.amax_out = w.amax;
+    a.amax_out = trunk_amax;
     JV_TRY(conv_gemm(a, 1, st));
     a = base_args(g, w.h, 256, e.final_proj, w.d, 80);
     a.rowmask_in = w.rowmask;
@@ -313,6 +315,7 @@ int flow_estimator(Context& c, const float* x, const int* lens_dev, const float*
   JV_TRY(row_meta(w.rowmask, w.row_sample, w.lens2, B2, 1, FLOW_G, g.S, T, w.rows_alloc, 1, 0, st));
   JV_HIP(hipMemcpyAsync(w.t_dev, t_dev, sizeof(float) * B2, hipMemcpyDeviceToDevice, st));
   JV_TRY(assemble_xin_plain(w.x, w.mu, spks, w.cond, w.xin, B2, FLOW_G, g.S, T, g.M, st));
+  JV_HIP(hipMemsetAsync(w.amax, 0, sizeof(float), st));
   JV_TRY(estimator_body(c, g, st));
   return rows_to_cf(w.d, 80, 0, FLOW_G, g.S, out, 80L * T, B2, 80, T, nullptr, st);
 }
@@ -367,6 +370,7 @@ int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spk
   JV_TRY(cf_to_rows(c.noise, 0, NOISE_FRAMES, B, 80, T, w.x, 80, 0, FLOW_G, g.S, temperature, nullptr, st));
 
   JV_HIP(hipMemsetAsync(w.step_ctr, 0, sizeof(int), st));
+  JV_HIP(hipMemsetAsync(w.amax, 0, sizeof(float), st));      // trunk bound: maximum over the whole solve
   JV_HIP(hipMemcpyAsync(w.spks, spks, sizeof(float) * 80 * B, hipMemcpyDeviceToDevice, st));
   g.t_ptr = w.t_cur;   // the same t for all 2B rows (stride 0)
   auto euler_step = [&](hipStream_t s) -> int {

@@ -165,7 +165,7 @@ int resblock(const ResBlockW& rb, int C, long rows, long alloc, const unsigned c
     ConvGemmArgs a = conv_args(in, C, alloc, rows, rb.c1[j], tmp, C, -(d * (k - 1) / 2), d, mask);
     a.pro = PRO_SNAKE; a.pro_alpha = rb.a1[j];
     h3_measured(a, rb.c1[j], j == 0 ? am_cur : am_r, rb.e1[j], h3 && rb.e1[j] > 0.f);
-    a.amax_out = am_tmp;
+    a.amax_out = h3 ? am_tmp : nullptr;
     JV_TRY(conv_gemm(a, 1, st));
     const bool last = j == 2;
     a = conv_args(tmp, C, alloc, rows, rb.c2[j], last ? dst : r, C, -((k - 1) / 2), 1, mask);
@@ -177,7 +177,7 @@ int resblock(const ResBlockW& rb, int C, long rows, long alloc, const unsigned c
       a.accumulate = accumulate;
     }
     h3_measured(a, rb.c2[j], am_tmp, rb.e2[j], h3 && rb.e2[j] > 0.f);
-    a.amax_out = last ? am_dst : am_r;
+    a.amax_out = h3 ? (last ? am_dst : am_r) : nullptr;
     JV_TRY(conv_gemm(a, 1, st));
     in = r;
   }
@@ -225,7 +225,7 @@ int hift_decode(Context& c, const float* mel, const float* s, const int* lens, i
   // conv_pre (k7, pad 3)
   {
     ConvGemmArgs a = conv_args(w.mel, 96, g.alloc[0], g.rows[0], h.conv_pre, w.x0, 512, -3, 1, w.mask[0]);
-    a.amax_out = w.amax + HiftWs::A_X0;
+    a.amax_out = h3 ? w.amax + HiftWs::A_X0 : nullptr;
     JV_TRY(conv_gemm(a, 1, st));
   }
   const float* prev = w.x0;
@@ -239,7 +239,7 @@ int hift_decode(Context& c, const float* mel, const float* s, const int* lens, i
       ConvGemmArgs a = conv_args(prev, prevC, g.alloc[i], g.rows[i], h.ups[i], w.x[i], UPS[i] * C, -1, 1, w.mask[i]);
       a.pro = PRO_LRELU; a.pro_slope = 0.1f;
       h3_measured(a, h.ups[i], am_prev, 0.f, h3);      // |leaky_relu(x)| <= |x|
-      a.amax_out = w.amax + HiftWs::A_X + i;
+      a.amax_out = h3 ? w.amax + HiftWs::A_X + i : nullptr;
       JV_TRY(conv_gemm(a, 1, st));
       if (i == 2) JV_TRY(reflect_fix(w.x[i], B, g.G[3], g.S[3], C, st));
     }
@@ -247,7 +247,7 @@ int hift_decode(Context& c, const float* mel, const float* s, const int* lens, i
     {
       ConvGemmArgs a = conv_args(stft + sd_off[i] * 32, sd_stride[i] * 32, g.rows[l], g.rows[l], h.src_down[i], w.si[i], C,
                                  0, 1, nullptr);
-      a.amax_out = w.amax + HiftWs::A_SI + i;
+      a.amax_out = h3 ? w.amax + HiftWs::A_SI + i : nullptr;
       JV_TRY(conv_gemm(a, 1, st));
       JV_TRY(resblock(h.src_rb[i], C, g.rows[l], g.alloc[l], w.mask[l], w.si[i], w.r[i], w.tmp[i], w.xs[i], w.x[i], 1.f, 0,
                       w.amax + HiftWs::A_SI + i, w.amax + HiftWs::A_R + i, w.amax + HiftWs::A_TMP + i,

@@ -152,6 +152,10 @@ __global__ __launch_bounds__(256) void ln_epilogue_kernel(float* __restrict__ x,
   f32x4 v[VPL];
   float sum = 0.f;
   unsigned amax = 0u;      // max |value written|, as conv_gemm's epilogue tracks it (ConvGemmArgs::amax_out)
+  // what the slot held when this wave started (it only grows, so a stale value is a valid lower bound); read here so
+  // that the load's latency hides behind the row loads instead of extending the wave's tail
+  // (a plain, cacheable load on purpose: twenty thousand waves polling one L2 line with a volatile load cost 8 us)
+  const unsigned seen = amax_out ? *reinterpret_cast<const unsigned*>(amax_out) : 0xffffffffu;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int c4 = lane + 64 * i;
@@ -193,11 +197,12 @@ __global__ __launch_bounds__(256) void ln_epilogue_kernel(float* __restrict__ x,
       for (int e = 0; e < 4; ++e) amax = max(amax, __float_as_uint(r[e]) & 0x7fffffffu);
     }
   }
-  if (amax_out) {
+  // wave-uniform: once the slot is warm no lane exceeds it, and the cross-lane reduction (six dependent LDS round trips at
+  // the very end of a one-row wave: +50 % on this bandwidth-bound kernel) is not entered at all
+  if (amax_out && __builtin_amdgcn_ballot_w64(amax > seen) != 0) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o));
-    if (lane == 0 && amax > *reinterpret_cast<volatile const unsigned*>(amax_out))
-      atomicMax(reinterpret_cast<unsigned*>(amax_out), amax);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(amax_out), amax);
   }
 }
 
