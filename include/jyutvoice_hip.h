@@ -82,13 +82,16 @@ int jv_flow_set_streaming(jv_context* ctx, int chunk_frames);
  * the GPU.  The in-library profiler (jv_profile_enable) forces the eager path because it brackets every
  * launch with events.  Results are bit-identical either way. */
 int jv_flow_set_graph(jv_context* ctx, int on);
-/* jv_flow_set_contraction: how the estimator's fp32 Linear layers (transformer.py:355-443: to_q/k/v, to_out, ff.net.0,
- * ff.net.2 -- 4 x 56 GEMMs per call) are contracted on the matrix cores.  exact_range = 0 (default): fp16x3 -- each
- * operand split into two fp16 planes after an exact power-of-two scaling (22 significant bits, three MFMA products,
- * fp32 accumulate) -- on exactly those layers whose input range is PROVEN at load time from the weights (LayerNorm
- * outputs, attention outputs, GELU of a bounded Linear); every other contraction, and all of them with exact_range = 1
- * (or JV_EXACT_RANGE=1 in the environment at jv_create), runs bf16x6 (three bf16 planes, 24 bits, six products), which
- * takes any fp32 operand.  Both meet the same operator-level bound against fp64 (tests/test_gpu_ops.py). */
+/* jv_flow_set_contraction: how fp32 contractions are carried out on the 16-bit matrix cores.  exact_range = 0
+ * (default): fp16x3 -- each operand split into two fp16 planes after an exact power-of-two scaling (22 significant bits,
+ * three MFMA products, fp32 accumulate) -- wherever an upper bound of the operand is known, so that fp16's range cannot be
+ * exceeded: PROVEN from the weights at load time for the estimator's Linear layers and attention (transformer.py:355-443:
+ * LayerNorm outputs, Linears of bounded inputs, attention outputs, GELU of a bounded Linear), MEASURED on the device by the
+ * kernels that produce the operand for the estimator's convolutions (decoder.py:110-115, 767-788) and the vocoder
+ * (generator.py:90-97, 396-432).  Every other contraction, and all of them with exact_range = 1 (or JV_EXACT_RANGE=1 in
+ * the environment at jv_create), runs bf16x6 (three bf16 planes, 24 bits, six products), which takes any fp32 operand.
+ * Both meet the same operator-level bound against fp64 (tests/test_gpu_ops.py).  Applies to this context's estimator,
+ * solver and vocoder calls. */
 int jv_flow_set_contraction(jv_context* ctx, int exact_range);
 /* jv_cfm_solve: CausalConditionalCFM.forward + ConditionalCFM.solve_euler (flow_matching.py:356-401, 215-265):
  * fixed noise prefix * temperature, cosine schedule, n_timesteps Euler steps with CFG rate 0.7.
