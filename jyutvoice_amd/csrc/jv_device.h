@@ -83,7 +83,11 @@ __device__ __forceinline__ float h3_scale_dev(const float bound) {
 __device__ __forceinline__ Split2 split2h_pair(const float x0, const float x1) {
   const jv_f32x2 x = {x0, x1};
   const jv_f16x2 h = __builtin_convertvector(x, jv_f16x2);
-  const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];
+  // x * 1 - h with a 1.0 the optimiser cannot see through: the residual then is ONE v_fma_mix_f32 per element (h read as
+  // fp16 in place, same exactly-rounded x - h) instead of v_cvt_f32_f16 + v_sub_f32
+  float one = 1.0f;
+  asm volatile("" : "+v"(one));
+  const float r0 = fmaf(x0, one, -(float)h[0]), r1 = fmaf(x1, one, -(float)h[1]);
   const jv_f32x2 r = {r0, r1};
   const jv_f16x2 l = __builtin_convertvector(r, jv_f16x2);
   return {__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, l)};
