@@ -55,8 +55,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed on {s}:\n{r.stdout}\n{r.stderr}")
         return s
 
+    jobs.sort(key=lambda j: 0 if 'conv_gemm_x6_t' in j[0] else 1)      # the long compiles first
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=max(1, min(6, (os.cpu_count() or 4) - 2, len(jobs)))) as ex:
             for s in ex.map(cc, jobs):
                 if verbose:
                     print(f"[jyutvoice_amd.build] compiled {os.path.basename(s)}", flush=True)

@@ -84,7 +84,7 @@ struct ConvGemmArgs {
   const float* W;
   const unsigned short* W3;   // optional: the same matrix as three bf16 planes [3][n_rows_w][ldw] (bf16x6 path)
   long w3_plane;              // elements between planes
-  // optional fp16x3 path (conv_gemm_x6.hip, NP = 2): W2 = two fp16 planes of W[n][:] * 2^e_n, colscale[n] = 2^-e_n, and a
+  // optional fp16x3 path (conv_gemm_x6_kernel.h, NP = 2): W2 = two fp16 planes of W[n][:] * 2^e_n, colscale[n] = 2^-e_n, and a
   // power of two a_scale with |A| * a_scale < 65504 PROVEN by the caller (a load-time bound, registry.hip); the kernel
   // returns acc * colscale[n] / a_scale.  Ignored unless W2 is set; plain prologue only.
   const unsigned short* W2;
@@ -150,7 +150,7 @@ struct ConvGemmArgs {
 void conv_gemm_defaults(ConvGemmArgs& a);
 int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st);
 int conv_gemm_init();   // raises the dynamic-LDS limit of every instantiation
-int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st);   // bf16x6 main loop (conv_gemm_x6.hip); needs a.W3
+int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st);   // split-plane main loops (conv_gemm_x6_kernel.h); needs a.W3
 
 // ---- in-library kernel profiler (profile.hip): HIP events around the hot kernels, on the launch stream ----------
 bool prof_on();

@@ -236,7 +236,7 @@ __global__ void tile_bias_kernel(const float* __restrict__ src, float* __restric
   if (i < n * reps) dst[i] = src[i % n];
 }
 
-// fp32 -> three bf16 planes (h, m, l) with x ~= h + m + l to 24 bits (conv_gemm_x6.hip)
+// fp32 -> three bf16 planes (h, m, l) with x ~= h + m + l to 24 bits (conv_gemm_x6_kernel.h)
 __global__ void split3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long n) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -592,7 +592,7 @@ int finalize_model(Context& c, int model, hipStream_t st) {
         w.n3 = pk.ln(b + "norm3.", "weight", "bias");
         w.ff1 = pk.linear(b + "ff.net.0.proj.weight", b + "ff.net.0.proj.bias", EST_FF, EST_CH);
         w.ff2 = pk.linear(b + "ff.net.2.weight", b + "ff.net.2.bias", EST_CH, EST_FF);
-        // fp16x3 where the input range is proven at load time (conv_gemm_x6.hip, NP = 2).  |LayerNorm_256(x) g + b| <=
+        // fp16x3 where the input range is proven at load time (conv_gemm_x6_kernel.h, NP = 2).  |LayerNorm_256(x) g + b| <=
         // sqrt(255) max|g| + max|b|; a Linear of a bounded input is bounded by its largest row L1 norm; attention
         // returns convex combinations of its V rows; |gelu(x)| <= |x|.
         const float b1 = 16.f * pk.host_maxabs(w.n1.g, EST_CH) + pk.host_maxabs(w.n1.b, EST_CH);

@@ -229,7 +229,7 @@ def test_x6_every_tile_variant(dev, x6, monkeypatch, tile):
 
 @pytest.mark.parametrize("tile,K", [("0", 1024), ("2", 1024), ("3", 256), ("4", 512)])
 def test_x6_weight_dma_race_screen(dev, x6, monkeypatch, tile, K):
-    """the weight planes reach LDS by LDS-DMA, ordered only by vmcnt + barrier (csrc/conv_gemm_x6.hip): a misplaced read
+    """the weight planes reach LDS by LDS-DMA, ordered only by vmcnt + barrier (csrc/conv_gemm_x6_kernel.h): a misplaced read
     shows up as rare wrong tiles, so every variant is replayed on a long K loop and must reproduce bit for bit -- and
     match fp64 -- while other work keeps the memory system busy"""
     from jyutvoice_amd.engine import op_conv_gemm
