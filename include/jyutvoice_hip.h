@@ -165,6 +165,7 @@ int jv_op_conv_gemm(const float* A, int64_t a_rows, int M, int Cin, int ntaps, i
                     const float* bias, int act, int prologue, const float* alpha, float slope, const float* ln_g,
                     const float* ln_b, float ln_eps, const uint8_t* rowmask, const float* res, float* out, void* stream);
 int jv_op_attention(const float* qkv, const int32_t* lens, int B, int G, int S, int L, float* out, void* stream);
+float jv_h3_scale_for_bound(float bound);   /* host only: the power of two chosen for a proven bound (0 = unusable) */
 int jv_op_conv_h3_measured(const float* A, int64_t a_rows, int M, int Cin, int ntaps, int tap_row0, int dil, const float* W,
                            int N, const float* bias, int act, int prologue, const float* alpha, float slope,
                            const uint8_t* rowmask, const float* res, const float* amax_in, float a_extra, float* amax_out,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "jv_hift_decode": (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
     "jv_op_conv_gemm": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _f, _p, _p, _f, _p, _p, _p, _p]),
     "jv_op_attention": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "jv_h3_scale_for_bound": (_f, [_f]),
     "jv_op_conv_h3_measured": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _f, _p, _p, _p, _f, _p, _p, _p]),
     "jv_op_attention_h3": (_i, [_p, _p, _i, _i, _i, _i, _f, _f, _f, _p, _p]),
     "jv_op_linear_h3": (_i, [_p, _i64, _i, _i, _p, _i, _p, _i, _p, _f, _i, _p, _p]),

@@ -242,6 +242,9 @@ int jv_op_conv_gemm(const float* A, int64_t a_rows, int M, int Cin, int ntaps, i
   return jv::conv_gemm(a, 1, static_cast<hipStream_t>(stream));
 }
 
+// host logic of the fp16x3 scale choice (no device work): largest power of two s with bound * s <= 60000, 0 = unusable
+float jv_h3_scale_for_bound(float bound) { return jv::h3_scale_for_bound(bound); }
+
 // y = act(A W^T + bias) (+ res) through the fp16x3 main loop; a_bound: the caller's proven bound on |A| (test hook)
 int jv_op_linear_h3(const float* A, int64_t rows, int M, int K, const float* W, int N, const float* bias, int act,
                     const float* res, float a_bound, int presplit, float* out, void* stream) {

@@ -66,3 +66,19 @@ def test_product_does_not_import_oracle():
             if re.search(r"^\s*(from|import)\s+oracle\b", open(f).read(), flags=re.M):
                 bad.append(f)
     assert not bad, bad
+
+
+def test_h3_scale_for_bound_host_logic(lib):
+    """the power of two the library derives from a proven bound (registry.hip; host only, no device needed): a power of
+    two, bound * s <= 60000 < 2 * bound * s within its clamp, and 0 -- 'keep this layer on bf16x6' -- for unusable bounds"""
+    import math
+    f = lib.jv_h3_scale_for_bound
+    for bound in (1e-3, 0.5, 1.0, 21.7, 280.0, 5.9e4, 6.0e4, 6.5e4, 3.0e7, 1e11):
+        s = f(bound)
+        assert s > 0 and math.log2(s) == int(math.log2(s)), (bound, s)
+        assert bound * s <= 60000.0
+        if 2.0 ** -24 < s < 2.0 ** 24:
+            assert 2.0 * bound * s > 60000.0, (bound, s)
+    assert f(21.7) == 2048.0 and f(280.0) == 128.0        # LayerNorm-fed and attention-output bounds of the synthetic weights
+    for bad in (0.0, -1.0, float("nan"), float("inf"), 1e31):
+        assert f(bad) == 0.0
