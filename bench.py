@@ -207,9 +207,13 @@ def main():
     if args.workload == "c3":
         assert wav.shape == (B, 480 * T) and torch.isfinite(wav).all(), wav.shape
     kern = {}
+    event_overhead_us = None
     if profile:
         engine.profile_enable(False)
         kern = engine.profile_report()
+        pair = kern.pop("_empty_event_pair", None)      # what an event pair measures around nothing
+        if pair:
+            event_overhead_us = 1e3 * pair["ms"]
     if use_dist:
         el = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -246,6 +250,9 @@ def main():
                             "steps, inside the timed region (jv_profile_*)",
                 "precision": precision,
             }
+            if event_overhead_us is not None:      # the fixed cost inside avg_launch_us; rocprofv3's kernel duration excludes it
+                out["roofline"]["event_pair_overhead_us"] = round(event_overhead_us, 2)
+                out["roofline"]["avg_launch_us_less_event_overhead"] = round(1e3 * d["ms"] / d["launches"] - event_overhead_us, 2)
             out["roofline"].update(pmc_traffic(name, args))
             def line(k, v):
                 e = {"launches": v["launches"], "ms_per_step": round(v["ms"] / prof_steps, 3)}
