@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_${TAG}_$ONLY
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export JV_ONLY=$ONLY JV_OP_X6=1
+export JV_ONLY=$ONLY JV_OP_X6=1      # add JV_OP_H3=1 in the environment for the fp16x3 forms
 i=0
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA" \
