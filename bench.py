@@ -5,8 +5,13 @@
 
 Workload (BASELINE.json configs[2], the one the metric is quoted on): full text encoder -> flow decoder (CFM Euler/CFG,
 n_timesteps = 10) -> HiFT vocoder, batch 32 utterances per GPU, 150 tokens -> 300 mel frames = 6.0 s of 24 kHz audio
-each, synthetic key-hashed weights and seeded inputs; fp32 data and fp32-level accuracy throughout
-(contractions as bf16x6 on the bf16 matrix cores, attention on the fp32 matrix cores).
+each, synthetic key-hashed weights and seeded inputs; fp32 data, fp32 accumulation, and contractions on
+the 16-bit matrix cores at fp32-level accuracy: fp16x3 (operands scaled by an exact power of two and split into two fp16
+planes = 22 significant bits, three MFMA products) wherever an upper bound of the operand is proven at load time or
+measured on the device, bf16x6 (three bf16 planes = 24 bits, six products) elsewhere.  `value` is measured
+in that default mode; `value_exact_range` repeats the timed loop with every contraction on bf16x6
+(jv_flow_set_contraction(1)), and `parity` carries the default mode's measured error against the CPU oracle on the
+utterances the CPU baseline synthesises anyway.
 One "step" = one pass of that path over one batch; inputs are resident in HBM before the timed region.
 With N > 1 (launched by torch.distributed.run, one rank per GPU) each rank synthesises its own 32 utterances (weak
 scaling, no data-path collective) and the generated mels are all-gathered over RCCL at the end of every step.
@@ -73,8 +78,12 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(n_tokens: int, n_timesteps: int, repeats: int):
-    """the oracle on the host: B = 1 sequential semantics (what the reference does), end to end"""
+def cpu_baseline(n_tokens: int, n_timesteps: int, repeats: int, hip=None):
+    """the oracle on the host: B = 1 sequential semantics (what the reference does), end to end.
+    hip (optional): {"mel" [B,80,T], "wav" [B,480T], "s" [B,1,480T]} CPU tensors of the benchmarked pass; utterance i of
+    the batch is the oracle's utterance i (same seeded inputs), so the timed oracle runs double as the parity check --
+    mel max-abs against the oracle's mel, waveform RMS against the oracle's vocoder on the HIP mel with the HIP source
+    signal (outside the timed part)."""
     import math
 
     import torch
@@ -98,17 +107,33 @@ def cpu_baseline(n_tokens: int, n_timesteps: int, repeats: int):
         phase[:, 0] = 0
         s = ohift.source(w, f0, phase, torch.randn(1, 9, 480 * T, generator=g))
         ohift.decode(w, mel, s)
+        mels[i] = mel
         return T
 
+    mels = {}
     with torch.inference_mode():
         one(0)                      # warm-up
         t0 = time.perf_counter()
         frames = sum(one(1 + i) for i in range(repeats))
         dt = time.perf_counter() - t0
-    return {"value": round(frames / dt, 2), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "rtf": round(dt / (frames * 0.02), 4),
-            "sample": f"{repeats} utterances x {n_tokens} tokens -> {frames // repeats} frames, n_timesteps={n_timesteps}, "
-                      f"B=1 sequential, encoder+CFM+HiFT, after 1 warm-up"}
+        parity = None
+        if hip is not None:
+            mel_err = wav_err = 0.0
+            for i, m in mels.items():
+                if i >= hip["mel"].shape[0]:
+                    continue
+                mel_err = max(mel_err, float((hip["mel"][i:i + 1] - m).abs().max()))
+                want = ohift.decode(w, hip["mel"][i:i + 1], hip["s"][i:i + 1])
+                wav_err = max(wav_err, float((hip["wav"][i:i + 1] - want).pow(2).mean().sqrt()))
+            parity = {"mel_max_abs": float(f"{mel_err:.3e}"), "wav_rms": float(f"{wav_err:.3e}"),
+                      "utterances": sorted(i for i in mels if i < hip["mel"].shape[0]),
+                      "tolerance": {"mel_max_abs": 1e-3, "wav_rms": 1e-4},
+                      "against": "CPU oracle (oracle/, B = 1 per utterance): its mel; its vocoder on the HIP mel with the HIP source signal"}
+    out = {"value": round(frames / dt, 2), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+           "rtf": round(dt / (frames * 0.02), 4),
+           "sample": f"{repeats} utterances x {n_tokens} tokens -> {frames // repeats} frames, n_timesteps={n_timesteps}, "
+                     f"B=1 sequential, encoder+CFM+HiFT, after 1 warm-up"}
+    return out, parity
 
 
 def main():
@@ -127,6 +152,7 @@ def main():
                     help="how many of the K timed steps carry the per-launch HIP events (each event pair costs GPU time: all "
                          "steps instrumented lowers `value` by ~5 %%; one step gives ~1700 launches of the dominant kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-range", action="store_true", help="skip the second timed loop (bf16x6 everywhere)")
     ap.add_argument("--cpu-utts", type=int, default=3)
     args = ap.parse_args()
 
@@ -171,38 +197,50 @@ def main():
         c2_cond = torch.zeros(B, 80, T, device=device)
         eng = get_runtime(device).ensure(B, T, Tt)
 
+    src = {}
+
     def step():
         if args.workload == "c2":
             mel = eng.cfm_solve(c2_mu, None, c2_spks, c2_cond, n_steps, 1.0)
             return {"mel": mel, "mel_lengths": None}, None
         res = tts.synthesise(batch["x"], batch["x_lengths"], batch["lang"], batch["tone"], batch["word_pos"],
                              batch["syllable_pos"], batch["spk_embed"], None, n_timesteps=n_steps, batched=True)
-        wav, _ = hift.inference(res["mel"])
+        wav, src["s"] = hift.inference(res["mel"])
         if use_dist:
             jdist.all_gather_mels(res["mel"], res["mel_lengths"])
         return res, wav
+
+    def timed_loop(n, profiled_steps=0):
+        """barrier + synchronize, exactly n steps, synchronize + barrier; MAX over ranks"""
+        torch.cuda.synchronize(device)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for i in range(n):
+            if profiled_steps and i == profiled_steps:
+                engine.profile_enable(False)     # events stay queued on the stream; read back after the timed region
+            out = step()
+        torch.cuda.synchronize(device)
+        if use_dist:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
 
     for _ in range(args.warmup):
         step()
 
     profile = not args.no_profile
     torch.cuda.synchronize(device)
-    if use_dist:
-        dist.barrier()
     if profile:
         engine.profile_report()          # drop anything recorded during warm-up
         engine.profile_enable(True)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
     prof_steps = min(max(1, args.profile_steps), args.steps) if profile else 0
-    for i in range(args.steps):
-        if profile and i == prof_steps:
-            engine.profile_enable(False)     # events stay queued on the stream; read back after the timed region
-        res, wav = step()
-    torch.cuda.synchronize(device)
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, (res, wav) = timed_loop(args.steps, prof_steps)
     assert res["mel"].shape == (B, 80, T) and torch.isfinite(res["mel"]).all(), res["mel"].shape
     if args.workload == "c3":
         assert wav.shape == (B, 480 * T) and torch.isfinite(wav).all(), wav.shape
@@ -214,10 +252,18 @@ def main():
         pair = kern.pop("_empty_event_pair", None)      # what an event pair measures around nothing
         if pair:
             event_overhead_us = 1e3 * pair["ms"]
-    if use_dist:
-        el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
+    hip_out = None
+    if args.workload == "c3" and rank == 0:
+        hip_out = {"mel": res["mel"].float().cpu(), "wav": wav.float().cpu(), "s": src["s"].float().cpu()}
+    # the same loop with every contraction on bf16x6 (24-bit operands): what the fp16x3 engine buys, measured, not claimed
+    elapsed_exact = None
+    if not args.no_exact_range and not os.environ.get("JV_EXACT_RANGE"):
+        rt_eng = get_runtime(device).ensure(B, T, Tt)
+        rt_eng.set_exact_range(True)
+        step()
+        elapsed_exact, (res_x, _) = timed_loop(args.steps)
+        assert torch.isfinite(res_x["mel"]).all()
+        rt_eng.set_exact_range(False)
 
     if rank == 0:
         frames = world * B * T * args.steps
@@ -225,7 +271,10 @@ def main():
             "metric": "mel_frames_per_sec", "value": round(frames / elapsed, 1), "unit": "mel-frames/s",
             "rtf": round(elapsed / (frames * 0.02), 6), "x_realtime": round(frames * 0.02 / elapsed, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 (bf16x6 split: 24-bit operands on the bf16 matrix cores, fp32 accumulate)" if os.environ.get("JV_EXACT_RANGE") else
+                      "f32 (fp16x3 split: 22-bit operands on the fp16 matrix cores where a bound exists, bf16x6 = 24-bit elsewhere; fp32 accumulate)"),
+            "data": "synthetic",
             "config": {"workload": ("C3: text encoder -> CFM flow decoder (Euler+CFG) -> HiFT vocoder, full synthesise()+inference()"
                                     if args.workload == "c3" else "C2: CFM flow decoder loop alone (Euler+CFG), N(0,1) mu, full mask"),
                        "utterances_per_gpu": B, "global_batch": B * world, "tokens": Tt, "mel_frames": T,
@@ -268,8 +317,15 @@ def main():
             out["kernels"] = {k: line(k, v) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}
             out["profiled_kernel_ms_per_step"] = round(tot_ms / prof_steps, 3)
             out["profiled_steps"] = prof_steps
+        if elapsed_exact is not None:
+            out["value_exact_range"] = round(frames / elapsed_exact, 1)
+            out["ms_per_step_exact_range"] = round(1e3 * elapsed_exact / args.steps, 3)
+            out["exact_range_note"] = ("the same timed loop with every contraction on bf16x6 (24-bit operands, "
+                                       "jv_flow_set_contraction(1)); `value` is the default fp16x3 mode")
         if world == 1 and not args.no_cpu_baseline and args.workload == "c3":
-            out["cpu_baseline"] = cpu_baseline(Tt, n_steps, args.cpu_utts)
+            out["cpu_baseline"], parity = cpu_baseline(Tt, n_steps, args.cpu_utts, hip_out)
+            if parity:
+                out["parity"] = parity
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -41,6 +41,12 @@ typedef struct jv_context jv_context;
  * at most max_batch utterances of max_frames mel frames / max_tokens text tokens per call. */
 int jv_create(jv_context** out, int device, int max_batch, int max_frames, int max_tokens);
 void jv_destroy(jv_context* ctx);
+/* jv_reserve: change the capacities of a live context.  Only the workspace (activation buffers, masks, captured step
+ * graphs) is re-created; loaded and finalized weights, the noise tensor and the mel filterbank stay where they are --
+ * nothing is uploaded or packed again.  Waits for the device to drain first (it frees buffers queued work may use), so
+ * pre-size once with the largest (batch, frames, tokens) a service expects rather than growing call by call.  The
+ * reference has no counterpart: its nn.Modules allocate activations per call (infer.py:419-433). */
+int jv_reserve(jv_context* ctx, int max_batch, int max_frames, int max_tokens);
 /* message of the last failing call on this thread (valid until the next failure) */
 const char* jv_last_error(void);
 

@@ -36,6 +36,7 @@ _i64 = C.c_int64
 SIGNATURES = {
     "jv_create": (_i, [C.POINTER(_p), _i, _i, _i, _i]),
     "jv_destroy": (None, [_p]),
+    "jv_reserve": (_i, [_p, _i, _i, _i]),
     "jv_last_error": (C.c_char_p, []),
     "jv_num_tensors": (_i, [_p]),
     "jv_tensor_name": (C.c_char_p, [_p, _i]),

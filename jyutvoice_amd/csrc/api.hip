@@ -51,6 +51,23 @@ using jv::Context;
     if (_e != hipSuccess) return jv::fail(JV_ERR_HIP, hipGetErrorString(_e)); \
   }
 
+// Everything whose size follows the capacities (max_batch, max_frames, max_tokens).  Weights (raw + packed arenas), the
+// noise tensor and the mel filterbank do not: jv_reserve re-creates only this, never re-uploads or re-packs a weight.
+static int workspaces_create(Context& c) {
+  int rc = jv::flow_ws_create(c);
+  if (rc == JV_OK) rc = jv::hift_ws_create(c);
+  if (rc == JV_OK) rc = jv::enc_ws_create(c);
+  return rc;
+}
+static void workspaces_destroy(Context& c) {
+  for (void* p : c.ws_allocs) (void)hipFree(p);
+  c.ws_allocs.clear();
+  jv::flow_ws_destroy(c);      // also drops captured Euler-step graphs: they point into the old buffers
+  jv::hift_ws_destroy(c);
+  jv::enc_ws_destroy(c);
+  jv::prompt_ws_destroy(c);    // sized on demand by its own calls (prompt.hip); capped by max_frames
+}
+
 extern "C" {
 
 const char* jv_last_error(void) { return jv::g_last_error.c_str(); }
@@ -80,10 +97,10 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   c.max_tokens = max_tokens;
   jv::build_registry(c);
   int rc = jv::conv_gemm_init();
-  if (rc == JV_OK) rc = jv::flow_ws_create(c);
-  if (rc == JV_OK) rc = jv::hift_ws_create(c);
-  if (rc == JV_OK) rc = jv::enc_ws_create(c);
-  if (rc == JV_OK) rc = jv::ws_alloc(c, sizeof(float) * jv::N_FEATS * jv::NOISE_FRAMES, reinterpret_cast<void**>(&c.noise));
+  if (rc == JV_OK) rc = workspaces_create(c);
+  // the noise tensor is a weight-like constant: it lives outside the workspace and survives jv_reserve
+  if (rc == JV_OK && hipMalloc(reinterpret_cast<void**>(&c.noise), sizeof(float) * jv::N_FEATS * jv::NOISE_FRAMES) != hipSuccess)
+    rc = jv::fail(JV_ERR_HIP, "jv_create: out of device memory (noise tensor)");
   if (rc != JV_OK) {
     jv_destroy(ctx);
     return rc;
@@ -92,18 +109,28 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   return JV_OK;
 }
 
+int jv_reserve(jv_context* ctx, int max_batch, int max_frames, int max_tokens) {
+  CTX_GUARD(ctx);
+  Context& c = ctx->c;
+  if (max_batch < 1 || max_frames < 1 || max_tokens < 1) return jv::fail(JV_ERR_ARG, "jv_reserve: capacities must be >= 1");
+  if (max_batch == c.max_batch && max_frames == c.max_frames && max_tokens == c.max_tokens) return JV_OK;
+  JV_HIP(hipDeviceSynchronize());      // nothing queued may still use the old workspace (or replay a graph that points into it)
+  workspaces_destroy(c);
+  c.max_batch = max_batch;
+  c.max_frames = max_frames;
+  c.max_tokens = max_tokens;
+  return workspaces_create(c);
+}
+
 void jv_destroy(jv_context* ctx) {
   if (!ctx) return;
   Context& c = ctx->c;
   (void)hipSetDevice(c.device);
   (void)hipDeviceSynchronize();
-  for (void* p : c.ws_allocs) (void)hipFree(p);
+  workspaces_destroy(c);
+  if (c.noise) (void)hipFree(c.noise);
   c.raw_arena.release();
   c.packed.release();
-  jv::flow_ws_destroy(c);
-  jv::hift_ws_destroy(c);
-  jv::enc_ws_destroy(c);
-  jv::prompt_ws_destroy(c);
   jv::audio_ws_destroy(c);
   delete ctx;
 }
@@ -178,24 +205,31 @@ int jv_flow_estimator_step(jv_context* ctx, const float* x, const int32_t* lens,
 }
 
 int jv_flow_set_streaming(jv_context* ctx, int chunk_frames) {
-  if (!ctx) return jv::fail(JV_ERR_ARG, "null context");
+  CTX_GUARD(ctx);
   if (chunk_frames < 0) return jv::fail(JV_ERR_ARG, "jv_flow_set_streaming: chunk must be >= 0");
   ctx->c.attn_chunk = chunk_frames;
   return JV_OK;
 }
 
 int jv_flow_set_graph(jv_context* ctx, int on) {
-  if (!ctx) return jv::fail(JV_ERR_ARG, "null context");
+  CTX_GUARD(ctx);
   ctx->c.step_graphs = on != 0;
-  if (!on) jv::flow_graphs_drop(ctx->c);
+  if (!on && jv::flow_has_graphs(ctx->c)) {
+    JV_HIP(hipDeviceSynchronize());      // a replay may still be executing on the private stream
+    jv::flow_graphs_drop(ctx->c);
+  }
   return JV_OK;
 }
 
+// A mode switch is a configuration call, not a hot-path one: it waits for everything this device has queued (solves on
+// any stream, graph replays) before it touches the workspace, so nothing in flight sees half of each mode.
 int jv_flow_set_contraction(jv_context* ctx, int exact_range) {
-  if (!ctx) return jv::fail(JV_ERR_ARG, "null context");
+  CTX_GUARD(ctx);
   if (ctx->c.exact_range != (exact_range != 0)) {
+    JV_HIP(hipDeviceSynchronize());
     jv::flow_graphs_drop(ctx->c);                  // captured steps hold the old kernels
     jv::flow_ws_forget_attention(ctx->c, nullptr);   // that buffer holds fp32 rows in one mode, fp16 planes in the other
+    JV_HIP(hipDeviceSynchronize());
   }
   ctx->c.exact_range = exact_range != 0;
   return JV_OK;

@@ -99,6 +99,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p, co
   f32x4 pa[NAMAX];
   f32x4 pw[NB];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  int2* const rowtab = reinterpret_cast<int2*>(reinterpret_cast<unsigned char*>(smem) + p.rowtab_off);
+  rowtab_fill<BM, false>(p, rowtab, m0);      // read by the epilogue (amax_out), behind the main loop's barriers
 
   auto load_A = [&](int c0) {
 #pragma unroll
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs p, co
     c = c1;
   }
 
-  conv_epilogue<WM, WN, EPI>(p, out, acc, smem, m0, n0, wm, wn, t_start, t_loop);
+  conv_epilogue<WM, WN, EPI>(p, out, acc, smem, m0, n0, wm, wn, t_start, t_loop, rowtab);
 }
 
 void conv_gemm_defaults(ConvGemmArgs& a) {
@@ -250,12 +252,15 @@ size_t lds_bytes(const ConvGemmArgs& a) {
 }
 
 template <int BM, int BN, int WM, int WN, int NAMAX, int PRO, int EPI>
-int launch2(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
+int launch2(const ConvGemmArgs& a_in, int nbatch, hipStream_t st) {
+  ConvGemmArgs a = a_in;
   const int win = BM + (a.ntaps - 1) * a.tap_dil;
   if (win > 32 * NAMAX) return fail(JV_ERR_ARG, "conv_gemm: window too tall for this tile variant");
   size_t lds = lds_bytes<BM, BN>(a);
   const size_t need = (size_t)4 * 32 * (WN + 4) * sizeof(float);
   if (lds < need) lds = need;
+  a.rowtab_off = (int)lds;
+  lds += (size_t)BM * sizeof(int2);
   const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
   dim3 grid(tiles_m * tiles_n, 1, nbatch);
   const bool prof = prof_on();
@@ -367,7 +372,7 @@ int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
     g.amax_out = nullptr;      // what stays in `out` is what the LayerNorm pass writes
     JV_TRY(conv_gemm(g, 1, st));
     return ln_epilogue_rows(a.out, a.ln_g, a.ln_b, a.ln_eps, a.M, a.N, a.act, a.rowmask_out, a.rowvec, a.row_sample,
-                            a.rowvec_ld, a.res1, a.ldr1, a.out_scale, st, a.amax_out);
+                            a.rowvec_ld, a.res1, a.ldr1, a.out_scale, st, a.amax_out, a.amax_G, a.amax_S, a.amax_nb);
   }
   if (const char* ab = tuning_env("JV_ABLATE")) const_cast<ConvGemmArgs&>(a).ablate = atoi(ab);
   if ((a.W3 || a.W2) && nbatch == 1 && (a.ldw & 7) == 0 && !dyn_env("JV_NO_X6")) return conv_gemm_x6(a, st);

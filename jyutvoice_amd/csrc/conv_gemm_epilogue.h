@@ -14,6 +14,54 @@ namespace jv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- per-row table of a tile (LDS, [BM] int2, filled at kernel start by rowtab_fill) -------------------------------
+// The measured fp16x3 bound (ConvGemmArgs::amax_in / amax_out) is kept PER UTTERANCE: slot(row) = (row - amax_G) / amax_S
+// clamped to [0, amax_nb) (one slot when amax_S == 0), so that an utterance's scales -- hence its results, bit for bit --
+// do not depend on what else is in the batch.  x = bits of 1 / a_scale of the row's slot (1.0 unless the launch derives
+// its scale from amax_in); y = the slot, with ROW_UNTRACKED set when the row's values must not enter amax_out (rows past
+// M, and rows that amax_mask marks as padding: their values are never read as real frames).
+constexpr int ROW_UNTRACKED = 1 << 30;
+__device__ __forceinline__ int amax_slot(const ConvGemmArgs& p, long row) {
+  if (p.amax_S <= 0) return 0;
+  const long s = (row - p.amax_G) / p.amax_S;
+  return (int)(s < 0 ? 0 : (s >= p.amax_nb ? p.amax_nb - 1 : s));
+}
+template <int BM, bool SC>
+__device__ __forceinline__ void rowtab_fill(const ConvGemmArgs& p, int2* tab, const int m0) {
+  const int t = threadIdx.x;
+  if (t < BM && (p.amax_out || (SC && p.amax_in))) {
+    const long m = (long)m0 + t;
+    const int slot = amax_slot(p, m);
+    float inv = 1.f;
+    if (SC && p.amax_in) inv = 1.0f / h3_scale_dev(p.amax_in[slot] + p.a_extra);
+    const bool tracked = p.amax_out && m < p.M && (!p.amax_mask || p.amax_mask[m] != 0);
+    tab[t] = int2{(int)__float_as_uint(inv), slot | (tracked ? 0 : ROW_UNTRACKED)};
+  }
+}
+// fold this wave's maxima (rmax[k] = max |value| the lane stored in tile row ridx[k]) into the slots of the tile rows
+// [first, last] the wave covered: one wave-level reduction and at most one atomic per slot, and none at all once the slot
+// already holds a larger value (wave-uniform branch; `seen0` = the slot of row `first` as prefetched by the caller)
+template <int NR>
+__device__ __forceinline__ void amax_flush(float* amax_out, const int2* tab, const int first, const int last,
+                                           const int (&ridx)[NR], const unsigned (&rmax)[NR], const unsigned seen0) {
+  const int lo = __builtin_amdgcn_readfirstlane(tab[first].y & (ROW_UNTRACKED - 1));
+  const int hi = __builtin_amdgcn_readfirstlane(tab[last].y & (ROW_UNTRACKED - 1));
+  for (int s = lo; s <= hi; ++s) {
+    unsigned u = 0u;
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+      if (tab[ridx[k]].y == s) u = max(u, rmax[k]);      // untracked rows carry the flag bit and never match
+    // (a plain, cacheable load on purpose: thousands of waves polling one L2 line with a volatile load serialise there;
+    // the slot only grows, so a stale value is a valid lower bound)
+    const unsigned seen = s == lo ? seen0 : *reinterpret_cast<const unsigned*>(amax_out + s);
+    if (__builtin_amdgcn_ballot_w64(u > seen) != 0) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o));
+      if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax_out + s), u);
+    }
+  }
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void epilogue_passes(F& f) {      // f(0), f(1), ... f(N-1) with compile-time indices
   if constexpr (I < N) {
@@ -31,7 +79,7 @@ template <int WM, int WN, int EPI, bool SC = false>
 __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out, f32x16 (&acc)[WM / 32][WN / 32], float* smem,
                                               const int m0, const int n0, const int wm, const int wn,
                                               unsigned long long t_start, unsigned long long t_loop,
-                                              const float a_scale = 1.f) {
+                                              const int2* tab, const float a_scale = 1.f) {
   constexpr int MT = WM / 32, NT = WN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, half = lane >> 5;
@@ -58,21 +106,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
       for (int e = 0; e < 4; ++e) bb[e] = (n + e < p.N) ? p.bias[n + e] : 0.f;
   }
   f32x4 cs = {1.f, 1.f, 1.f, 1.f};
+  const bool rowscale = SC && p.amax_in != nullptr;      // measured bound: 1 / a_scale is per row (rowtab), else uniform
   if constexpr (SC) {
-    const float inv = 1.0f / a_scale;        // powers of two: exact
+    const float inv = rowscale ? 1.f : 1.0f / a_scale;        // powers of two: exact
 #pragma unroll
     for (int e = 0; e < 4; ++e) cs[e] = (n + e < p.N) ? p.colscale[n + e] * inv : 0.f;
   }
   // p.amax_out: max |value| over everything this thread stores, kept as the bit pattern of the non-negative float --
   // unsigned order is numeric order there, with inf and NaN on top, so the integer max propagates them
-  unsigned amax = 0u;
-  // the slot's value when the epilogue starts (it only grows: a stale read is a valid lower bound), fetched before the
-  // slab work so that its latency is hidden
-  // (a plain, cacheable load on purpose: thousands of waves polling one L2 line with a volatile load serialise there)
-  const unsigned seen = p.amax_out ? *reinterpret_cast<const unsigned*>(p.amax_out) : 0xffffffffu;
-  auto track = [&](const f32x4& t) {
+  auto amax4 = [](const f32x4& t) {
+    unsigned a = 0u;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) amax = max(amax, __float_as_uint(t[e]) & 0x7fffffffu);
+    for (int e = 0; e < 4; ++e) a = max(a, __float_as_uint(t[e]) & 0x7fffffffu);
+    return a;
   };
   auto pass = [&](auto mt_tag) {
     constexpr int mt = decltype(mt_tag)::value;
@@ -88,9 +134,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
       // out = act(acc + bias) (+ res1).  All residual loads of the pass are issued before any arithmetic.
       constexpr bool E_GELU = (EPI & 1) != 0, E_RES = (EPI & 2) != 0, E_PL = (EPI & 8) != 0;
       const int mrow = m0 + wm * WM + mt * 32 + rsub;
+      const int trow0 = wm * WM + mt * 32;      // first tile row of the pass (index into the row table)
+      unsigned seen0 = 0xffffffffu;
+      if (p.amax_out) seen0 = *reinterpret_cast<const unsigned*>(p.amax_out + (tab[trow0].y & (ROW_UNTRACKED - 1)));
+      int ridx[NIT];
+      unsigned rmax[NIT];
       f32x4 x[NIT], r[NIT];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) x[it] = *reinterpret_cast<const f32x4*>(slab + (it * RPI + rsub) * ES + col);
+      for (int it = 0; it < NIT; ++it) {
+        ridx[it] = trow0 + it * RPI + rsub;
+        rmax[it] = 0u;
+        x[it] = *reinterpret_cast<const f32x4*>(slab + (it * RPI + rsub) * ES + col);
+        if constexpr (SC) {
+          if (rowscale) x[it] = x[it] * __uint_as_float((unsigned)tab[ridx[it]].x);      // 1 / a_scale of the row's utterance
+        }
+      }
       if constexpr (E_RES) {
         const float* rb = p.res1 + (long)mrow * p.ldr1 + n;
 #pragma unroll
@@ -118,9 +176,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
         } else
         if (nin && mrow + it * RPI < p.M && !JV_ABLATE(p, 64)) {
           *reinterpret_cast<f32x4*>(ob + (long)(it * RPI) * p.ldo) = t;
-          if (p.amax_out) track(t);
+          rmax[it] = amax4(t);
         }
       }
+      if (p.amax_out) amax_flush<NIT>(p.amax_out, tab, trow0, trow0 + 31, ridx, rmax, seen0);
       return;
     }
 #pragma unroll 1
@@ -128,12 +187,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
       f32x4 x[UN], r1[UN], r2[UN], pv[UN];
       bool ok[UN], keep[UN];
       int sample[UN];
+      const int trow0 = wm * WM + mt * 32 + it0 * RPI;      // first tile row of this group
+      unsigned seen0 = 0xffffffffu;
+      if (p.amax_out) seen0 = *reinterpret_cast<const unsigned*>(p.amax_out + (tab[trow0].y & (ROW_UNTRACKED - 1)));
+      int ridx[UN];
+      unsigned rmax[UN];
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
         const int row = (it0 + u) * RPI + rsub;
         const int m = m0 + wm * WM + mt * 32 + row;
         ok[u] = nin && m < p.M;
+        ridx[u] = wm * WM + mt * 32 + row;
+        rmax[u] = 0u;
         x[u] = *reinterpret_cast<const f32x4*>(slab + row * ES + col);
+        if constexpr (SC) {
+          if (rowscale) x[u] = x[u] * __uint_as_float((unsigned)tab[ridx[u]].x);
+        }
         r1[u] = zero4; r2[u] = zero4; pv[u] = zero4;
         keep[u] = true;
         sample[u] = 0;
@@ -179,7 +248,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (n + e >= p.N) tr[e] = 0.f;
-          track(tr);
+          rmax[u] = amax4(tr);
         }
         if (vec) {
           if (!JV_ABLATE(p, 64) || res[0] == 12345.678f) *reinterpret_cast<f32x4*>(o) = res;
@@ -188,18 +257,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
             if (n + e < p.N) o[e] = res[e];
         }
       }
+      // (18 K workgroups x 4 waves each sending an atomic to one address cost 0.5 ms per launch before amax_flush's check)
+      if (p.amax_out) amax_flush<UN>(p.amax_out, tab, trow0, trow0 + UN * RPI - 1, ridx, rmax, seen0);
     }
   };
   epilogue_passes<0, MT>(pass);
-  // one atomic per wave, and only from waves that saw something larger than the slot held (wave-uniform branch: once
-  // the slot is warm the reduction is skipped altogether)
-  if (p.amax_out && __builtin_amdgcn_ballot_w64(amax > seen) != 0) {
-    unsigned u = amax;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o));
-    // (18 K workgroups x 4 waves each sending an atomic to the one address cost 0.5 ms per launch before the check)
-    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(p.amax_out), u);
-  }
   if (JV_STAMP(p)) t_p0 = __builtin_amdgcn_s_memtime();
   if (JV_STAMP(p) && tid == 0) {
     unsigned long long* d = p.stamps + (size_t)blockIdx.x * 4;

@@ -70,8 +70,9 @@ template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int NWB, in
 __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EPI != 4) ? 5 : 2) void conv_gemm_x6_kernel(const ConvGemmArgs p, const int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = WM / 32, NT = WN / 32;
-  // fp16x3 scale of A: the caller's (proven at load time) or derived here from the measured maximum of the buffer
-  const float a_scale = NP == 2 ? (p.amax_in ? h3_scale_dev(*p.amax_in + p.a_extra) : p.a_scale) : 1.f;
+  // fp16x3 scale of A: the caller's (proven at load time), or -- per staged row, below -- derived from the measured
+  // maximum of the row's utterance (p.amax_in)
+  const float a_scale = NP == 2 ? p.a_scale : 1.f;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
   static_assert(NWB == 1 || NWB == 2, "one or two weight buffers");
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
   // advance set to 0: the loop body is branch-free.
   const float* asrc[NR];
   int astep[NR];
+  float ascale[NR];      // fp16x3: the power of two this thread's window row is staged with
 #pragma unroll
   for (int i = 0; i < (APL ? 0 : NR); ++i) {
     const int r = arow + 128 * i;
@@ -118,7 +120,12 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
     if (ok && p.rowmask_in) ok = p.rowmask_in[ar] != 0;
     asrc[i] = ok ? A + ar * p.lda + koff : jv_zero_page;
     astep[i] = ok ? 1 : 0;
+    // every tap row of a real output row belongs to that row's utterance (the gaps between utterances are at least a
+    // window wide) or is masked to zero, so staging with the input row's slot and un-scaling with the output row's agree
+    ascale[i] = (NP == 2 && p.amax_in) ? h3_scale_dev(p.amax_in[amax_slot(p, ar)] + p.a_extra) : a_scale;
   }
+  int2* const rowtab = reinterpret_cast<int2*>(reinterpret_cast<unsigned char*>(smem) + p.rowtab_off);
+  rowtab_fill<BM, NP == 2>(p, rowtab, m0);      // read by the epilogue, many barriers from here
 
   f32x4 pa[NR][2 * NG];
 
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
             u32x4 h, l;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const Split2 t = split2h_pair(x[2 * e] * a_scale, x[2 * e + 1] * a_scale);
+              const Split2 t = split2h_pair(x[2 * e] * ascale[i], x[2 * e + 1] * ascale[i]);
               h[e] = t.h;
               l[e] = t.l;
             }
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
     c = c2;
   }
   __syncthreads();
-  conv_epilogue<WM, WN, EPI, NP == 2>(p, out, acc, smem, m0, n0, wm, wn, t_start, t_loop, a_scale);
+  conv_epilogue<WM, WN, EPI, NP == 2>(p, out, acc, smem, m0, n0, wm, wn, t_start, t_loop, rowtab, a_scale);
 }
 
 namespace {
@@ -319,7 +326,7 @@ size_t x6_lds_bytes(const ConvGemmArgs& a, int nwb = 1) {
 }
 
 template <int BM, int BN, int WM, int WN, int PRO, int EPI, int NA2, int NWB, int NP>
-int x6_launch4(const ConvGemmArgs& a, hipStream_t st) {
+int x6_launch4(const ConvGemmArgs& a_in, hipStream_t st) {
   static bool raised[64] = {};      // per device: the attribute belongs to the kernel's image on the current device
   int dev = 0;
   JV_HIP(hipGetDevice(&dev));
@@ -328,9 +335,12 @@ int x6_launch4(const ConvGemmArgs& a, hipStream_t st) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     raised[dev & 63] = true;
   }
+  ConvGemmArgs a = a_in;
   size_t lds = x6_lds_bytes<BM, BN>(a, NWB);
   const size_t need = (size_t)4 * 32 * (WN + 4) * sizeof(float);
   if (lds < need) lds = need;
+  a.rowtab_off = (int)lds;                     // per-row table (conv_gemm_epilogue.h) behind the images and the slabs
+  lds += (size_t)BM * sizeof(int2);
   const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
   const bool prof = prof_on();
   if (prof) prof_begin(st);

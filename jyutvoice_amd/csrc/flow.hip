@@ -24,10 +24,14 @@ struct FlowWs {
   float *xin = nullptr;                                               // [rows,320]
   float *h = nullptr, *h2 = nullptr, *res = nullptr, *cat = nullptr;  // [rows,256] x3, [rows,512]
   float *ln = nullptr, *qkv = nullptr, *att = nullptr, *ff = nullptr; // 256, 1536, 512, 1024
-  // max |value| written to the trunk buffers (h, h2, cat) during the current estimator call: every kernel that writes one
-  // of them tracks it (ConvGemmArgs::amax_out, ln_epilogue_rows), and the convolutions that read them -- whose input, the
-  // residual stream, has no load-time bound -- derive their fp16x3 scale from it (amax_in).  Zeroed once per solve.
+  // max |value| written to the trunk buffers during the current solve, one slot per BUFFER (h, h2, cat: a launch never
+  // reads the slot it writes) and per UTTERANCE (CFG twins count as utterances of their own: [3][2 * max_batch] floats):
+  // every kernel that writes one of them tracks it (ConvGemmArgs::amax_out, ln_epilogue_rows), and the convolutions that
+  // read them -- whose input, the residual stream, has no load-time bound -- derive their fp16x3 scale from it (amax_in).
+  // An utterance's scales therefore depend on that utterance alone: its result is the same bit for bit whatever else is
+  // in the batch and however a batch is sharded over GPUs.  Zeroed once per solve.
   float* amax = nullptr;
+  int amax_stride = 0;      // floats per buffer = 2 * max_batch
   float *d = nullptr;                                                 // [rows,80]
   float *tsin = nullptr, *t1 = nullptr, *tmish = nullptr, *temb = nullptr;
   float *t_dev = nullptr, *t_table = nullptr, *dt_table = nullptr;
@@ -74,7 +78,8 @@ int flow_ws_create(Context& c) {
   JV_TRY(F(&w->t1, (size_t)B2 * 1024));
   JV_TRY(F(&w->tmish, (size_t)B2 * 1024));
   JV_TRY(F(&w->temb, (size_t)B2 * EST_NRES * 256));
-  JV_TRY(F(&w->amax, 4));
+  w->amax_stride = B2;
+  JV_TRY(F(&w->amax, (size_t)3 * B2));
   JV_TRY(F(&w->t_dev, (size_t)B2));
   JV_TRY(F(&w->t_table, (size_t)w->max_steps));
   JV_TRY(F(&w->dt_table, (size_t)w->max_steps));
@@ -89,6 +94,8 @@ int flow_ws_create(Context& c) {
   JV_HIP(hipEventCreateWithFlags(&w->ev_out, hipEventDisableTiming));
   return JV_OK;
 }
+
+bool flow_has_graphs(const Context& c) { return c.flow && !c.flow->graphs.empty(); }
 
 void flow_graphs_drop(Context& c) {
   if (!c.flow) return;
@@ -159,13 +166,28 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.tap_row0 = -2;
     a.rowmask_in = w.rowmask;
   };
+  float* skip = w.cat + 256;   // columns [256,512) of the concat buffer
   // trunk convolutions: fp16x3 from the measured bound of the trunk buffers (not for A = xin, which assemble_xin writes)
   // (zeroed by the caller once per solve, not per call: in the first launch after a reset every wave sends its atomic --
   // the per-CU L1 keeps serving the value the slot had at kernel start -- which cost 2.4 ms per step when done ten times)
-  float* const trunk_amax = c.exact_range ? nullptr : w.amax;      // nothing consumes it in exact-range mode
+  auto slots_of = [&](const float* buf) -> float* {
+    if (buf == w.h) return w.amax;
+    if (buf == w.h2) return w.amax + w.amax_stride;
+    if (buf == w.cat || buf == skip) return w.amax + 2 * w.amax_stride;
+    return nullptr;
+  };
+  auto amax_geo = [&](ConvGemmArgs& a) { a.amax_G = FLOW_G; a.amax_S = g.S; a.amax_nb = B2; a.amax_mask = w.rowmask; };
+  // every launch that writes a trunk buffer tracks max |value| into that buffer's slots (nothing consumes them in
+  // exact-range mode)
+  auto track = [&](ConvGemmArgs& a) {
+    if (c.exact_range) return;
+    a.amax_out = slots_of(a.out);
+    amax_geo(a);
+  };
   auto h3m = [&](ConvGemmArgs& a, const GemmW& m) {
-    if (c.exact_range || !m.w2 || a.A == w.xin) return;
-    a.W2 = m.w2; a.w2_plane = (long)m.n_rows * m.ldw; a.colscale = m.colscale; a.amax_in = w.amax; a.a_extra = 0.f;
+    if (c.exact_range || !m.w2 || a.A == w.xin || !slots_of(a.A)) return;
+    a.W2 = m.w2; a.w2_plane = (long)m.n_rows * m.ldw; a.colscale = m.colscale; a.amax_in = slots_of(a.A); a.a_extra = 0.f;
+    amax_geo(a);
   };
   // CausalResnetBlock1D (decoder.py:110-115, 784-795)
   auto resnet = [&](int i, const float* in, int ldin, float* out, int ldo) -> int {
@@ -176,7 +198,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.rowmask_out = w.rowmask;
     a.rowvec = w.temb + i * 256; a.row_sample = w.row_sample; a.rowvec_ld = EST_NRES * 256;
     h3m(a, r.block1);
-    a.amax_out = trunk_amax;      // -> h2
+    track(a);      // -> h2
     JV_TRY(conv_gemm(a, 1, st));
     a = base_args(g, in, ldin, r.res, w.res, 256);
     a.rowmask_in = w.rowmask;
@@ -188,7 +210,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.rowmask_out = w.rowmask;
     a.res1 = w.res; a.ldr1 = 256;
     h3m(a, r.block2);
-    a.amax_out = trunk_amax;      // -> h
+    track(a);      // -> h
     return conv_gemm(a, 1, st);
   };
   // BasicTransformerBlock (transformer.py:355-443): h -> h, last GEMM may retarget its output
@@ -222,7 +244,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     JV_TRY(attention64(at, st));
     a = base_args(g, w.att, 512, b.out, h, 256);
     a.res1 = h; a.ldr1 = 256;
-    a.amax_out = trunk_amax;      // -> h
+    track(a);      // -> h
     h3(a, b.out);
     if (pre(b.out)) planes_in(a, w.att, 512);
     JV_TRY(conv_gemm(a, 1, st));
@@ -238,13 +260,12 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     JV_TRY(conv_gemm(a, 1, st));
     a = base_args(g, w.ff, 1024, b.ff2, out, ldo);
     a.res1 = h; a.ldr1 = 256;
-    a.amax_out = trunk_amax;      // -> h / cat
+    track(a);      // -> h / cat
     h3(a, b.ff2);
     if (ff_planes) planes_in(a, w.ff, 1024);
     return conv_gemm(a, 1, st);
   };
 
-  float* skip = w.cat + 256;   // columns [256,512) of the concat buffer
   // down: resnet -> 4 blocks (result doubles as the skip) -> causal conv
   JV_TRY(resnet(0, w.xin, 320, w.h, 256));
   for (int j = 0; j < EST_NBLK; ++j) JV_TRY(btb(e.blk[0][j], w.h, j == EST_NBLK - 1 ? skip : w.h, j == EST_NBLK - 1 ? 512 : 256));
@@ -252,7 +273,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     ConvGemmArgs a = base_args(g, skip, 512, e.down_conv, w.h, 256);
     causal3(a);
     h3m(a, e.down_conv);
-    a.amax_out = trunk_amax;
+    track(a);
     JV_TRY(conv_gemm(a, 1, st));
   }
   // mid x12; the last block writes straight into columns [0,256) of the concat buffer
@@ -270,14 +291,14 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     ConvGemmArgs a = base_args(g, w.h, 256, e.up_conv, w.h2, 256);
     causal3(a);
     h3m(a, e.up_conv);
-    a.amax_out = trunk_amax;
+    track(a);
     JV_TRY(conv_gemm(a, 1, st));
     a = base_args(g, w.h2, 256, e.final_conv, w.h, 256);
     causal3(a);
     a.ln = 1; a.ln_g = e.final_ln.g; a.ln_b = e.final_ln.b; a.ln_eps = 1e-5f; a.act = ACT_MISH;
     a.rowmask_out = w.rowmask;
     h3m(a, e.final_conv);
-    a.amax_out = trunk_amax;
+    track(a);
     JV_TRY(conv_gemm(a, 1, st));
     a = base_args(g, w.h, 256, e.final_proj, w.d, 80);
     a.rowmask_in = w.rowmask;
@@ -315,7 +336,7 @@ int flow_estimator(Context& c, const float* x, const int* lens_dev, const float*
   JV_TRY(row_meta(w.rowmask, w.row_sample, w.lens2, B2, 1, FLOW_G, g.S, T, w.rows_alloc, 1, 0, st));
   JV_HIP(hipMemcpyAsync(w.t_dev, t_dev, sizeof(float) * B2, hipMemcpyDeviceToDevice, st));
   JV_TRY(assemble_xin_plain(w.x, w.mu, spks, w.cond, w.xin, B2, FLOW_G, g.S, T, g.M, st));
-  JV_HIP(hipMemsetAsync(w.amax, 0, sizeof(float), st));
+  JV_HIP(hipMemsetAsync(w.amax, 0, sizeof(float) * 3 * w.amax_stride, st));
   JV_TRY(estimator_body(c, g, st));
   return rows_to_cf(w.d, 80, 0, FLOW_G, g.S, out, 80L * T, B2, 80, T, nullptr, st);
 }
@@ -370,7 +391,7 @@ int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spk
   JV_TRY(cf_to_rows(c.noise, 0, NOISE_FRAMES, B, 80, T, w.x, 80, 0, FLOW_G, g.S, temperature, nullptr, st));
 
   JV_HIP(hipMemsetAsync(w.step_ctr, 0, sizeof(int), st));
-  JV_HIP(hipMemsetAsync(w.amax, 0, sizeof(float), st));      // trunk bound: maximum over the whole solve
+  JV_HIP(hipMemsetAsync(w.amax, 0, sizeof(float) * 3 * w.amax_stride, st));      // trunk bounds: maxima over the whole solve
   JV_HIP(hipMemcpyAsync(w.spks, spks, sizeof(float) * 80 * B, hipMemcpyDeviceToDevice, st));
   g.t_ptr = w.t_cur;   // the same t for all 2B rows (stride 0)
   auto euler_step = [&](hipStream_t s) -> int {

@@ -39,9 +39,11 @@ struct HiftWs {
   float* frac = nullptr;                     // [B, 9, 480 T]
   unsigned char* mask[4] = {};
   int* lens = nullptr;
-  // max |value| ever written to a buffer during the current decode (device floats, zeroed at its start; conv_gemm's
-  // amax_out): the measured bound from which the consuming fp16x3 convolution derives its scale (amax_in)
+  // max |value| ever written to a buffer during the current decode, per buffer and per UTTERANCE ([A_SLOTS][max_batch]
+  // device floats, zeroed at its start; conv_gemm's amax_out): the measured bound from which the consuming fp16x3
+  // convolution derives its scale (amax_in) -- an utterance's waveform does not depend on its batch neighbours
   float* amax = nullptr;
+  int amax_stride = 0;      // = max_batch
   enum Slot { A_X0 = 0, A_SI = 1, A_R = 4, A_TMP = 7, A_XS = 10, A_X = 13, A_SLOTS = 16 };
 };
 
@@ -72,7 +74,8 @@ int hift_ws_create(Context& c) {
   JV_TRY(F(&w->frac, (size_t)c.max_batch * 9 * 480 * c.max_frames));
   for (int l = 0; l < 4; ++l) JV_TRY(ws_alloc(c, R0 * LVL_MUL[l], reinterpret_cast<void**>(&w->mask[l])));
   JV_TRY(ws_alloc(c, sizeof(int) * c.max_batch, reinterpret_cast<void**>(&w->lens)));
-  JV_TRY(ws_alloc(c, sizeof(float) * HiftWs::A_SLOTS, reinterpret_cast<void**>(&w->amax)));
+  w->amax_stride = c.max_batch;
+  JV_TRY(ws_alloc(c, sizeof(float) * HiftWs::A_SLOTS * c.max_batch, reinterpret_cast<void**>(&w->amax)));
   return JV_OK;
 }
 
@@ -146,6 +149,12 @@ int mel_to_rows(Context& c, const HGeo& g, const float* mel, hipStream_t st) {
   return cf_to_rows(mel, 80L * g.T, g.T, g.B, 80, g.T, c.hws->mel, 96, 0, H_G0, g.S0, 1.f, c.hws->lens, st);
 }
 
+// the per-utterance slot geometry of the rows at `lvl` (ConvGemmArgs::amax_G/S/nb); rows the level's mask marks as
+// padding are not tracked
+void amax_geo(ConvGemmArgs& a, const HGeo& g, int lvl, const unsigned char* mask) {
+  a.amax_G = g.G[lvl]; a.amax_S = g.S[lvl]; a.amax_nb = g.B; a.amax_mask = mask;
+}
+
 // fp16x3 on a convolution whose input bound is measured (am_in) and whose prologue adds at most `extra` to |x|
 void h3_measured(ConvGemmArgs& a, const GemmW& w, const float* am_in, float extra, bool on) {
   if (!on || !w.w2 || !am_in) return;
@@ -155,8 +164,8 @@ void h3_measured(ConvGemmArgs& a, const GemmW& w, const float* am_in, float extr
 
 // ResBlock (generator.py:90-97) of kernel k on [rows, C]: cur -> (result scaled/accumulated into dst, + extra residual)
 // am_*: the amax slots of cur, r, tmp and dst (HiftWs::amax); h3: fp16x3 allowed (not exact-range mode)
-int resblock(const ResBlockW& rb, int C, long rows, long alloc, const unsigned char* mask, const float* cur, float* r,
-             float* tmp, float* dst, const float* extra_res, float scale, int accumulate, float* am_cur, float* am_r,
+int resblock(const ResBlockW& rb, const HGeo& g, int lvl, int C, long rows, long alloc, const unsigned char* mask, const float* cur,
+             float* r, float* tmp, float* dst, const float* extra_res, float scale, int accumulate, float* am_cur, float* am_r,
              float* am_tmp, float* am_dst, bool h3, hipStream_t st) {
   const int dils[3] = {1, 3, 5};
   const float* in = cur;
@@ -166,6 +175,7 @@ int resblock(const ResBlockW& rb, int C, long rows, long alloc, const unsigned c
     a.pro = PRO_SNAKE; a.pro_alpha = rb.a1[j];
     h3_measured(a, rb.c1[j], j == 0 ? am_cur : am_r, rb.e1[j], h3 && rb.e1[j] > 0.f);
     a.amax_out = h3 ? am_tmp : nullptr;
+    amax_geo(a, g, lvl, mask);
     JV_TRY(conv_gemm(a, 1, st));
     const bool last = j == 2;
     a = conv_args(tmp, C, alloc, rows, rb.c2[j], last ? dst : r, C, -((k - 1) / 2), 1, mask);
@@ -178,6 +188,7 @@ int resblock(const ResBlockW& rb, int C, long rows, long alloc, const unsigned c
     }
     h3_measured(a, rb.c2[j], am_tmp, rb.e2[j], h3 && rb.e2[j] > 0.f);
     a.amax_out = h3 ? (last ? am_dst : am_r) : nullptr;
+    amax_geo(a, g, lvl, mask);
     JV_TRY(conv_gemm(a, 1, st));
     in = r;
   }
@@ -219,17 +230,19 @@ int hift_decode(Context& c, const float* mel, const float* s, const int* lens, i
   JV_TRY(mel_to_rows(c, g, mel, st));
   float* stft = w.stft_alloc + 16 * 32;
   JV_TRY(stft_rows(s, stft, w.lens, B, T, g.G[3], g.S[3], g.alloc[3], st));
-  JV_HIP(hipMemsetAsync(w.amax, 0, sizeof(float) * HiftWs::A_SLOTS, st));
+  JV_HIP(hipMemsetAsync(w.amax, 0, sizeof(float) * HiftWs::A_SLOTS * w.amax_stride, st));
   const bool h3 = !c.exact_range;
+  auto am = [&](int slot) { return w.amax + (long)slot * w.amax_stride; };
 
   // conv_pre (k7, pad 3)
   {
     ConvGemmArgs a = conv_args(w.mel, 96, g.alloc[0], g.rows[0], h.conv_pre, w.x0, 512, -3, 1, w.mask[0]);
-    a.amax_out = h3 ? w.amax + HiftWs::A_X0 : nullptr;
+    a.amax_out = h3 ? am(HiftWs::A_X0) : nullptr;
+    amax_geo(a, g, 0, w.mask[0]);
     JV_TRY(conv_gemm(a, 1, st));
   }
   const float* prev = w.x0;
-  float* am_prev = w.amax + HiftWs::A_X0;
+  float* am_prev = am(HiftWs::A_X0);
   int prevC = 512;
   const int sd_stride[3] = {15, 3, 1}, sd_off[3] = {-8, -2, 0};
   for (int i = 0; i < 3; ++i) {
@@ -239,7 +252,8 @@ int hift_decode(Context& c, const float* mel, const float* s, const int* lens, i
       ConvGemmArgs a = conv_args(prev, prevC, g.alloc[i], g.rows[i], h.ups[i], w.x[i], UPS[i] * C, -1, 1, w.mask[i]);
       a.pro = PRO_LRELU; a.pro_slope = 0.1f;
       h3_measured(a, h.ups[i], am_prev, 0.f, h3);      // |leaky_relu(x)| <= |x|
-      a.amax_out = h3 ? w.amax + HiftWs::A_X + i : nullptr;
+      a.amax_out = h3 ? am(HiftWs::A_X + i) : nullptr;
+      amax_geo(a, g, i, w.mask[i]);      // rows of the INPUT level: output row r carries the UPS[i] frames it expands to
       JV_TRY(conv_gemm(a, 1, st));
       if (i == 2) JV_TRY(reflect_fix(w.x[i], B, g.G[3], g.S[3], C, st));
     }
@@ -247,19 +261,19 @@ int hift_decode(Context& c, const float* mel, const float* s, const int* lens, i
     {
       ConvGemmArgs a = conv_args(stft + sd_off[i] * 32, sd_stride[i] * 32, g.rows[l], g.rows[l], h.src_down[i], w.si[i], C,
                                  0, 1, nullptr);
-      a.amax_out = h3 ? w.amax + HiftWs::A_SI + i : nullptr;
+      a.amax_out = h3 ? am(HiftWs::A_SI + i) : nullptr;
+      amax_geo(a, g, l, w.mask[l]);
       JV_TRY(conv_gemm(a, 1, st));
-      JV_TRY(resblock(h.src_rb[i], C, g.rows[l], g.alloc[l], w.mask[l], w.si[i], w.r[i], w.tmp[i], w.xs[i], w.x[i], 1.f, 0,
-                      w.amax + HiftWs::A_SI + i, w.amax + HiftWs::A_R + i, w.amax + HiftWs::A_TMP + i,
-                      w.amax + HiftWs::A_XS + i, h3, st));
+      JV_TRY(resblock(h.src_rb[i], g, l, C, g.rows[l], g.alloc[l], w.mask[l], w.si[i], w.r[i], w.tmp[i], w.xs[i], w.x[i], 1.f, 0,
+                      am(HiftWs::A_SI + i), am(HiftWs::A_R + i), am(HiftWs::A_TMP + i), am(HiftWs::A_XS + i), h3, st));
     }
     // x = xs now holds x_up + si ; MRF: mean of the three ResBlocks, accumulated into w.x[i]
     for (int j = 0; j < 3; ++j)
-      JV_TRY(resblock(h.rb[3 * i + j], C, g.rows[l], g.alloc[l], w.mask[l], w.xs[i], w.r[i], w.tmp[i], w.x[i], nullptr,
-                      1.f / 3.f, j > 0 ? 1 : 0, w.amax + HiftWs::A_XS + i, w.amax + HiftWs::A_R + i,
-                      w.amax + HiftWs::A_TMP + i, w.amax + HiftWs::A_X + i, h3, st));
+      JV_TRY(resblock(h.rb[3 * i + j], g, l, C, g.rows[l], g.alloc[l], w.mask[l], w.xs[i], w.r[i], w.tmp[i], w.x[i], nullptr,
+                      1.f / 3.f, j > 0 ? 1 : 0, am(HiftWs::A_XS + i), am(HiftWs::A_R + i), am(HiftWs::A_TMP + i),
+                      am(HiftWs::A_X + i), h3, st));
     prev = w.x[i];
-    am_prev = w.amax + HiftWs::A_X + i;
+    am_prev = am(HiftWs::A_X + i);
     prevC = C;
   }
   // leaky_relu (default slope 0.01) -> conv_post (k7) -> exp / sin -> iSTFT -> clamp

@@ -123,11 +123,12 @@ __global__ __launch_bounds__(256) void stft_rows_kernel(const float* __restrict_
   for (int i = 0; i < 8; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const long rel = r - G3;
   if (rel >= 0) {
-    const int b = (int)(rel / S3);
-    const long tau = rel - (long)b * S3;
+    const long bl = rel / S3;      // rows past the batch exist whenever the context's capacity exceeds this call's batch:
+    const int b = bl < B ? (int)bl : B - 1;      // never index lens[] / s with them
+    const long tau = rel - bl * S3;
     const int len = lens ? min(lens[b], T) : T;
     const long nvalid = (long)len * 480;
-    if (b < B && tau <= (long)len * 120 && nvalid > 0) {
+    if (bl < B && tau <= (long)len * 120 && nvalid > 0) {
       const float* sb = s + (long)b * T * 480;
       float x[16];
 #pragma unroll

@@ -98,8 +98,16 @@ struct ConvGemmArgs {
   const float* amax_in;
   float a_extra;
   // optional: atomic max of |value| over everything this launch writes (bit pattern of a non-negative float), for the
-  // consumer's amax_in.  The slot must be zeroed by the caller before the first producer of the buffer runs.
+  // consumer's amax_in.  The slot must be zeroed by the caller before the first producer of the buffer runs, and must not
+  // be the slot this launch reads (amax_in): every buffer has its own.
   float* amax_out;
+  // Both bounds are kept PER UTTERANCE so that an utterance's scales -- and with them its results, bit for bit -- do not
+  // depend on what else is in the batch: amax_in / amax_out point at amax_nb floats and row r (input and output rows share
+  // the row geometry) uses slot clamp((r - amax_G) / amax_S, 0, amax_nb - 1); amax_S = 0: one slot.  amax_mask (optional,
+  // per output row): rows with 0 are padding whose values never reach a real frame and are left out of amax_out.
+  int amax_G, amax_S, amax_nb;
+  const unsigned char* amax_mask;
+  int rowtab_off;      // set by the launcher: byte offset of the tile's per-row table in dynamic LDS (conv_gemm_epilogue.h)
   // optional with W2 (linears, ntaps = 1): A already split by its producer -- two fp16 planes [2][a_rows][lda2] of
   // A * a_scale (LayerNorm, attention and the GELU epilogue write them, same bytes as the fp32 rows); both operands then
   // reach LDS by LDS-DMA and the main loop has no VALU work and one barrier per step

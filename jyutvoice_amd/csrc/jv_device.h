@@ -75,8 +75,12 @@ __device__ __forceinline__ Split3 split3_pair(const float x0, const float x1) {
 typedef _Float16 jv_f16x2 __attribute__((ext_vector_type(2)));
 struct Split2 { unsigned h, l; };
 // largest power of two s with bound * s <= 60000 (the host's h3_scale_for_bound, registry.hip), for a bound measured on
-// the device: the exponent of 60000 / bound with the mantissa cleared; NaN / inf bounds give NaN / 0 and so propagate
+// the device: the exponent of 60000 / bound with the mantissa cleared.  A bound that is not finite (the producer already
+// wrote inf or NaN: the integer max of bit patterns propagates both into the slot) gives scale 0 ON PURPOSE: every output
+// of the utterance that owns the slot then comes out NaN (acc * colscale / 0), i.e. the fault stays visible and stays
+// inside that utterance -- fmaxf(NaN, x) would have returned x and scaled the finite rows into fp16 overflow silently.
 __device__ __forceinline__ float h3_scale_dev(const float bound) {
+  if (!(bound <= 3.0e38f)) return 0.f;
   const float q = 60000.f / fmaxf(bound, 1e-30f);
   return fminf(__uint_as_float(__float_as_uint(q) & 0xff800000u), 16777216.f);
 }

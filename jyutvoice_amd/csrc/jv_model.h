@@ -152,6 +152,7 @@ int ws_alloc(Context& c, size_t bytes, void** out);
 // flow.hip
 int flow_ws_create(Context& c);
 void flow_ws_forget_attention(Context& c, hipStream_t st);   // zero the attention buffer (new weights / contraction mode)
+bool flow_has_graphs(const Context& c);
 void flow_graphs_drop(Context& c);   // forget captured Euler-step graphs (weights or workspace pointers changed)
 int flow_estimator(Context& c, const float* x, const int* lens_dev, const float* mu, const float* t_dev, const float* spks,
                    const float* cond, int B2, int T, float* out, hipStream_t st);

@@ -20,7 +20,8 @@ int euler_cfg(float* x, const float* d, int B, int G, int S, int L, const float*
               hipStream_t st);
 int ln_epilogue_rows(float* x, const float* g, const float* b, float eps, long rows, int C, int act,
                      const unsigned char* rowmask, const float* rowvec, const int* row_sample, int rowvec_ld, const float* res,
-                     long ldr, float scale, hipStream_t st, float* amax_out = nullptr);
+                     long ldr, float scale, hipStream_t st, float* amax_out = nullptr, int amax_G = 0, int amax_S = 0,
+                     int amax_nb = 1);
 int fill(float* p, float v, long n, hipStream_t st);
 int fill_int(int* p, int v, long n, hipStream_t st);
 

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void ln_epilogue_kernel(float* __restrict__ x,
                                                           const unsigned char* __restrict__ rowmask,
                                                           const float* __restrict__ rowvec, const int* __restrict__ row_sample,
                                                           int rowvec_ld, const float* __restrict__ res, long ldr, float scale,
-                                                          float* __restrict__ amax_out) {
+                                                          float* __restrict__ amax_out, int amax_G, int amax_S, int amax_nb) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -152,6 +152,11 @@ __global__ __launch_bounds__(256) void ln_epilogue_kernel(float* __restrict__ x,
   f32x4 v[VPL];
   float sum = 0.f;
   unsigned amax = 0u;      // max |value written|, as conv_gemm's epilogue tracks it (ConvGemmArgs::amax_out)
+  // the row's utterance owns the slot (ConvGemmArgs::amax_G/S/nb); rows the mask marks as padding are not tracked
+  if (amax_out && amax_S > 0) {
+    const long sl = (row - amax_G) / amax_S;
+    amax_out += sl < 0 ? 0 : (sl >= amax_nb ? amax_nb - 1 : sl);
+  }
   // what the slot held when this wave started (it only grows, so a stale value is a valid lower bound); read here so
   // that the load's latency hides behind the row loads instead of extending the wave's tail
   // (a plain, cacheable load on purpose: twenty thousand waves polling one L2 line with a volatile load cost 8 us)
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(256) void ln_epilogue_kernel(float* __restrict__ x,
   }
   // wave-uniform: once the slot is warm no lane exceeds it, and the cross-lane reduction (six dependent LDS round trips at
   // the very end of a one-row wave: +50 % on this bandwidth-bound kernel) is not entered at all
-  if (amax_out && __builtin_amdgcn_ballot_w64(amax > seen) != 0) {
+  if (amax_out && keep && __builtin_amdgcn_ballot_w64(amax > seen) != 0) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o));
     if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(amax_out), amax);
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256) void ln_epilogue_kernel(float* __restrict__ x,
 
 int ln_epilogue_rows(float* x, const float* g, const float* b, float eps, long rows, int C, int act,
                      const unsigned char* rowmask, const float* rowvec, const int* row_sample, int rowvec_ld, const float* res,
-                     long ldr, float scale, hipStream_t st, float* amax_out) {
+                     long ldr, float scale, hipStream_t st, float* amax_out, int amax_G, int amax_S, int amax_nb) {
   if (rows <= 0) return JV_OK;
   if ((C & 3) || C > 1024 || (rowvec && (rowvec_ld & 3)) || (res && (ldr & 3)))
     return fail(JV_ERR_ARG, "ln_epilogue_rows: C, rowvec_ld and ldr must be multiples of 4 (C <= 1024)");
@@ -217,10 +222,10 @@ int ln_epilogue_rows(float* x, const float* g, const float* b, float eps, long r
   if (prof) prof_begin(st);
   if (C <= 256)
     hipLaunchKernelGGL((ln_epilogue_kernel<1>), grid, dim3(256), 0, st, x, g, b, eps, rows, C, act, rowmask, rowvec, row_sample,
-                       rowvec_ld, res, ldr, scale, amax_out);
+                       rowvec_ld, res, ldr, scale, amax_out, amax_G, amax_S, amax_nb);
   else
     hipLaunchKernelGGL((ln_epilogue_kernel<4>), grid, dim3(256), 0, st, x, g, b, eps, rows, C, act, rowmask, rowvec, row_sample,
-                       rowvec_ld, res, ldr, scale, amax_out);
+                       rowvec_ld, res, ldr, scale, amax_out, amax_G, amax_S, amax_nb);
   if (prof) prof_end(st, "ln_epilogue", 0.0, 4.0 * rows * C * (res ? 3 : 2));
   JV_HIP(hipGetLastError());
   return JV_OK;

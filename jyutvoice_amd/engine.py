@@ -45,6 +45,11 @@ class Engine:
         self._h = h
         self._loaded = {JV_MODEL_TTS: False, JV_MODEL_HIFT: False, JV_MODEL_PROMPT: False}
 
+    def reserve(self, max_batch, max_frames, max_tokens):
+        """grow (or shrink) the workspace of the live context; weights stay loaded (jv_reserve)"""
+        check(self.lib.jv_reserve(self._h, int(max_batch), int(max_frames), int(max_tokens)))
+        self.max_batch, self.max_frames, self.max_tokens = max_batch, max_frames, max_tokens
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.jv_destroy(self._h)

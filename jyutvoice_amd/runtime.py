@@ -1,5 +1,7 @@
 """Per-GPU runtime shared by the mirror classes: one library context holding both models' packed weights and
-a workspace that grows on demand (the C ABI sizes its workspace at jv_create)."""
+a workspace that grows on demand.  Growth (jv_reserve) re-creates the activation buffers only -- weights are uploaded and
+packed once per load_state_dict -- but it drains the device and reallocates, so a service should call
+`get_runtime(dev).ensure(max_batch, max_frames, max_tokens)` once up front, as bench.py does."""
 from __future__ import annotations
 
 from typing import Dict, Optional
@@ -24,21 +26,29 @@ class Runtime:
 
     def set_weights(self, model: int, sd: Dict[str, torch.Tensor]):
         """validate + upload a state-dict (raises like nn.Module.load_state_dict)"""
+        fresh = model not in self.sds
         self.sds[model] = {k: v.detach() for k, v in sd.items()}
         if self.engine is None:
             self.ensure(1, 512, 256)
+        elif fresh:
+            self.engine.load_state_dict(model, self.sds[model], strict=True)      # the other models' weights stay in place
         else:
-            self._rebuild(self.caps)
+            self._rebuild(self.caps)      # re-loading a finalized model: the C ABI wants a new context
 
     def ensure(self, batch: int, frames: int, tokens: int) -> Engine:
         need = (batch, frames, tokens)
         if self.engine is not None and all(n <= c for n, c in zip(need, self.caps)):
             return self.engine
         caps = (max(batch, self.caps[0]), _round_up(max(frames, self.caps[1]), 64), _round_up(max(tokens, self.caps[2]), 32))
-        self._rebuild(caps)
+        if self.engine is None:
+            self._rebuild(caps)
+        else:
+            self.engine.reserve(*caps)      # workspace only: the weights of both models stay where they are
+            self.caps = caps
         return self.engine
 
     def _rebuild(self, caps):
+        """new context + upload of every known state-dict: only when WEIGHTS change (the C ABI finalizes a model once)"""
         if self.engine is not None:
             self.engine.close()
             self.engine = None

@@ -94,3 +94,36 @@ def test_capacity_errors_are_loud(eng):
                            torch.zeros(2, 80, 2000))
     with pytest.raises(JvError, match="capacity"):
         eng.hift_decode(torch.zeros(9, 80, 4), torch.zeros(9, 1, 1920))
+
+
+def test_reserve_grows_workspace_and_keeps_weights(eng):
+    """jv_reserve: a different capacity re-creates the workspace only -- same context, no weight upload or re-packing --
+    and results before and after are identical bit for bit; a call beyond the capacity is refused loudly"""
+    g = torch.Generator().manual_seed(21)
+    mu = torch.randn(2, 80, 40, generator=g).cuda()
+    spks = torch.randn(2, 80, generator=g).cuda()
+    cond = torch.zeros(2, 80, 40).cuda()
+    handle = eng._h.value
+    before = eng.cfm_solve(mu, None, spks, cond, 3, 1.0).clone()
+    eng.reserve(7, 1164, 64)
+    assert eng._h.value == handle
+    assert torch.equal(eng.cfm_solve(mu, None, spks, cond, 3, 1.0), before)
+    eng.reserve(1, 64, 32)
+    with pytest.raises(Exception, match="capacity"):
+        eng.cfm_solve(mu, None, spks, cond, 3, 1.0)
+    eng.reserve(4, 1100, 64)
+    assert torch.equal(eng.cfm_solve(mu, None, spks, cond, 3, 1.0), before)
+
+
+def test_runtime_grows_without_reloading(tts_sd, hift_sd):
+    """Runtime.ensure on a live runtime keeps its context (one weight upload per load_state_dict)"""
+    import jyutvoice_amd
+    from jyutvoice_amd.runtime import get_runtime
+    tts, hift = jyutvoice_amd.build_default("cuda:0")
+    tts.load_state_dict(tts_sd)
+    hift.load_state_dict(hift_sd)
+    rt = get_runtime("cuda:0")
+    e0 = rt.engine
+    caps = rt.caps
+    e1 = rt.ensure(caps[0] + 1, caps[1] + 64, caps[2] + 32)
+    assert e1 is e0 and rt.caps[0] == caps[0] + 1

@@ -436,3 +436,23 @@ def test_h3_measured_bound_extremes(dev):
     Z = torch.zeros(M, K, device=dev)
     out = op_conv_h3_measured(Z, W, None, amax_in=torch.zeros(1, device=dev))
     assert float(out.abs().max()) == 0.0
+
+
+def test_h3_measured_bound_not_finite(dev):
+    """a producer that already wrote inf or NaN leaves that bit pattern in the slot (integer max of bit patterns); the
+    consumer then returns NaN for the rows of that slot ON PURPOSE (scale 0: jv_device.h h3_scale_dev) instead of scaling
+    the finite rows into fp16 overflow with a scale derived from a NaN"""
+    from jyutvoice_amd.engine import op_conv_h3_measured
+    g = torch.Generator().manual_seed(4)
+    M, K, N = 128, 128, 64
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    A = torch.randn(M, K, generator=g).to(dev)
+    for bad in (float("nan"), float("inf")):
+        out = op_conv_h3_measured(A, W, None, amax_in=torch.tensor([bad], device=dev))
+        assert torch.isnan(out).all(), bad
+    # tracking propagates a NaN written by the producer into the slot
+    A2 = A.clone()
+    A2[5, 7] = float("nan")
+    slot = torch.zeros(1, device=dev)
+    op_conv_h3_measured(A2, W, None, amax_out=slot)
+    assert not torch.isfinite(slot).all()

@@ -15,7 +15,8 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY 
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   i=$((i + 1))
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 $ROOT/tools/gemm_bench.py > $OUT/p$i.out 2> $OUT/p$i.err || { tail -5 $OUT/p$i.err; }
+  # a failed pass must not end up summarised as if it were complete (profile.sh exits the same way)
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 $ROOT/tools/gemm_bench.py > $OUT/p$i.out 2> $OUT/p$i.err || { echo "pass $i FAILED"; tail -20 $OUT/p$i.err; exit 1; }
   echo "pass $i done"
 done
 python3 $ROOT/tools/pmc_summary.py $OUT | tee $OUT/SUMMARY.md
