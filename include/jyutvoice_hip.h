@@ -180,6 +180,13 @@ int jv_op_attention_h3(const float* qkv, const int32_t* lens, int B, int G, int 
                        float v_bound, float* out, void* stream);
 int jv_op_linear_h3(const float* A, int64_t rows, int M, int K, const float* W, int N, const float* bias, int act,
                     const float* res, float a_bound, int presplit, float* out, void* stream);
+/* jv_op_rowgemm: the row-owning fp16x3 GEMM the estimator's transformer linears run on at batch sizes that fill the chip
+ * (transformer.py:355-443), with each epilogue: epi 0 plain -> out fp32 [M,N]; 1 exact GELU -> out2 = fp16 planes
+ * [2][M][N] of value * out2_scale; 2 + res -> out; 3 + res -> out, then LayerNorm_256 -> out2 = planes [2][M][256].
+ * a_bound: the caller's bound on |A|; presplit = 2 reuses the previous call's A planes (timing).  N % 256 == 0, K % 32 == 0. */
+int jv_op_rowgemm(const float* A, int64_t rows, int M, int K, const float* W, int N, const float* bias, int epi,
+                  const float* res, const float* ln_g, const float* ln_b, float a_bound, float out2_scale, int presplit,
+                  float* out, uint16_t* out2, float* amax_out, void* stream);
 int jv_op_layernorm(const float* x, const float* g, const float* b, float eps, int64_t rows, int C, float* out,
                     void* stream);
 

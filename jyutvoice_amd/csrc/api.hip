@@ -7,8 +7,11 @@
 #include "../../include/jyutvoice_hip.h"
 #include "jv_model.h"
 #include "jv_ops.h"
+#include "rowgemm_kernel.h"
 
 namespace jv {
+
+int rowgemm(const RowGemmArgs& a, int epi, hipStream_t st);   // rowgemm.hip
 
 int split3_planes(const float* src, unsigned short* dst, long n, hipStream_t st);   // registry.hip
 int split2h_planes(const float* src, int rows, int ld, float* stats, unsigned short* dst, float* colscale, hipStream_t st);
@@ -93,6 +96,8 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   c.step_graphs = getenv("JV_STEP_GRAPH") != nullptr;
   c.exact_range = getenv("JV_EXACT_RANGE") != nullptr;
   c.dma_a = getenv("JV_DMA_A") != nullptr;
+  c.no_rowgemm = getenv("JV_NO_ROWGEMM") != nullptr;
+  c.rg_ff1 = getenv("JV_RG_FF1") != nullptr;
   c.max_frames = max_frames;
   c.max_tokens = max_tokens;
   jv::build_registry(c);
@@ -384,6 +389,48 @@ int jv_op_attention_h3(const float* qkv, const int32_t* lens, int B, int G, int 
   at.v_scale = jv::h3_scale_for_bound(v_bound);
   if (!(at.q_scale > 0.f && at.k_scale > 0.f && at.v_scale > 0.f)) return jv::fail(JV_ERR_ARG, "jv_op_attention_h3: unusable bound");
   return jv::attention64(at, static_cast<hipStream_t>(stream));
+}
+
+// the row-owning fp16x3 GEMM (rowgemm_kernel.h) with each of its epilogues (test / tuning hook): A [rows,K] fp32 is split
+// into planes here (presplit = 2: reuse the planes of the previous call, timing only); epi: 0 plain, 1 GELU -> planes,
+// 2 + res, 3 + res -> LayerNorm -> planes.  out: fp32 [M,N] (epi 0, 2, 3); out2: planes [2][M][N] (epi 1) / [2][M][256] (epi 3)
+int jv_op_rowgemm(const float* A, int64_t rows, int M, int K, const float* W, int N, const float* bias, int epi,
+                  const float* res, const float* ln_g, const float* ln_b, float a_bound, float out2_scale, int presplit,
+                  float* out, uint16_t* out2, float* amax_out, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float sc = jv::h3_scale_for_bound(a_bound);
+  if (!(sc > 0.f)) return jv::fail(JV_ERR_ARG, "jv_op_rowgemm: unusable bound");
+  static void* scratch = nullptr;
+  static size_t cap = 0;
+  const size_t n = (size_t)N * K;
+  const size_t need = n * 4 + (size_t)N * 12 + 256;
+  if (need > cap) {
+    if (scratch) (void)hipFree(scratch);
+    JV_HIP(hipMalloc(&scratch, need));
+    cap = need;
+  }
+  unsigned short* planes = static_cast<unsigned short*>(scratch);
+  float* cs = reinterpret_cast<float*>(static_cast<char*>(scratch) + ((n * 4 + 63) & ~(size_t)63));
+  JV_TRY(jv::split2h_planes(W, N, K, cs + N, planes, cs, st));
+  static unsigned short* ap = nullptr;
+  static size_t acap = 0;
+  const size_t an = (size_t)rows * K;
+  if (an * 4 > acap) {
+    if (ap) (void)hipFree(ap);
+    JV_HIP(hipMalloc(reinterpret_cast<void**>(&ap), an * 4));
+    acap = an * 4;
+  }
+  if (presplit != 2) JV_TRY(jv::split2h_rows(A, K, ap, (long)an, rows, K, sc, st));
+  jv::RowGemmArgs a{};
+  a.A2 = ap; a.a2_plane = (long)an; a.a_rows = rows; a.lda2 = K;
+  a.M = M; a.K = K; a.N = N;
+  a.W2 = planes; a.w2_plane = (long)n; a.ldw = K; a.colscale = cs; a.a_scale = sc; a.bias = bias;
+  a.out = out; a.ldo = N; a.res = res; a.ldr = N;
+  a.out2 = out2; a.out2_plane = (long)M * (epi == jv::RG_RES_LN ? 256 : N); a.ldo2 = epi == jv::RG_RES_LN ? 256 : N;
+  a.out2_scale = out2_scale;
+  a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
+  a.amax_out = amax_out;
+  return jv::rowgemm(a, epi, st);
 }
 
 int jv_op_layernorm(const float* x, const float* g, const float* b, float eps, int64_t rows, int C, float* out, void* stream) {

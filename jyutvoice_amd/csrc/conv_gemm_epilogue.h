@@ -161,7 +161,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& p, float* out,
         f32x4 t = SC ? x[it] * cs + bb : x[it] + bb;
         if constexpr (E_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) t[e] = 0.5f * t[e] * (1.f + erff(t[e] * 0.70710678118654752440f));
+          for (int e = 0; e < 4; ++e) t[e] = gelu_erf(t[e]);
         }
         if constexpr (E_RES) t += r[it];
         if constexpr (E_PL) {

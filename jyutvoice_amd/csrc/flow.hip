@@ -12,8 +12,12 @@
 
 #include "jv_model.h"
 #include "jv_ops.h"
+#include "rowgemm_kernel.h"
 
 namespace jv {
+
+int rowgemm(const RowGemmArgs& a, int epi, hipStream_t st);   // rowgemm.hip
+int rowgemm_tile(int M);
 
 constexpr int FLOW_G = 4;      // leading guard rows (>= causal left context 2)
 constexpr int FLOW_GAP = 4;    // rows between utterances
@@ -265,10 +269,85 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     if (ff_planes) planes_in(a, w.ff, 1024);
     return conv_gemm(a, 1, st);
   };
+  // ---- the same block on the row-owning GEMM (rowgemm_kernel.h) when the batch fills the chip: every linear takes its A
+  // operand as the fp16 planes its producer wrote (LayerNorm, attention, the previous linear's epilogue), to_out and
+  // ff.net.2 add the residual AND run the LayerNorm that follows in their epilogue, ff.net.0 applies GELU and writes
+  // ff.net.2's operand: four GEMM launches + attention per block, no stand-alone row-wise kernel except the first
+  // LayerNorm of a stage.  `next`: the block that follows in the same stage (its norm1 runs in this block's last epilogue).
+  const bool use_rg = !c.exact_range && !c.no_rowgemm && rowgemm_tile((int)g.M) > 0;
+  auto rg_ok = [&](const BtbW& b) {
+    return b.qkv.w2 && b.out.w2 && b.ff1.w2 && b.ff2.w2 && b.qkv.a_scale > 0.f && b.out.a_scale > 0.f && b.ff1.a_scale > 0.f &&
+           b.ff2.a_scale > 0.f && b.q_scale > 0.f;
+  };
+  auto rg_args = [&](const float* planes, int K, const GemmW& m) {
+    RowGemmArgs a{};
+    a.A2 = reinterpret_cast<const unsigned short*>(planes); a.a2_plane = R * K; a.a_rows = g.a_rows; a.lda2 = K;
+    a.M = (int)g.M; a.K = K; a.N = m.N;
+    a.W2 = m.w2; a.w2_plane = (long)m.n_rows * m.ldw; a.ldw = m.ldw; a.colscale = m.colscale; a.a_scale = m.a_scale;
+    a.bias = m.bias; a.ln_eps = 1e-5f; a.out2_scale = 1.f;
+    a.alg_rows = (long)g.B2 * g.T;
+    return a;
+  };
+  auto rg_track = [&](RowGemmArgs& a) {
+    a.amax_out = slots_of(a.out); a.row_slot = w.row_sample; a.row_mask = w.rowmask;
+  };
+  auto btb_rg = [&](const BtbW& b, const BtbW* next, bool ln_ready, float* h, float* out, int ldo) -> int {
+    if (!ln_ready) JV_TRY(layernorm256_planes(h, reinterpret_cast<unsigned short*>(w.ln), R * 256, b.qkv.a_scale, b.n1.g, b.n1.b, 1e-5f, g.M, st));
+    RowGemmArgs a = rg_args(w.ln, 256, b.qkv);
+    a.out = w.qkv; a.ldo = 1536;
+    JV_TRY(rowgemm(a, RG_PLAIN, st));
+    AttnArgs at{};
+    at.qkv = w.qkv; at.ld = 1536; at.k_off = 512; at.v_off = 1024; at.out = w.att; at.ldo = 512;
+    at.B = B2; at.H = EST_HEADS; at.G = FLOW_G; at.S = g.S; at.L = g.T; at.lens = w.lens2;
+    at.chunk = c.attn_chunk;
+    at.q_scale = b.q_scale; at.k_scale = b.k_scale; at.v_scale = b.v_scale;
+    at.out2 = reinterpret_cast<unsigned short*>(w.att); at.out2_plane = R * 512; at.out2_scale = b.out.a_scale;
+    JV_TRY(attention64(at, st));
+    a = rg_args(w.att, 512, b.out);      // h += to_out(att); ln = LayerNorm3(h)
+    a.out = h; a.ldo = 256; a.res = h; a.ldr = 256;
+    a.out2 = reinterpret_cast<unsigned short*>(w.ln); a.out2_plane = R * 256; a.ldo2 = 256; a.out2_scale = b.ff1.a_scale;
+    a.ln_g = b.n3.g; a.ln_b = b.n3.b;
+    rg_track(a);
+    JV_TRY(rowgemm(a, RG_RES_LN, st));
+    if (c.rg_ff1) {
+      a = rg_args(w.ln, 256, b.ff1);       // ff = gelu(ff.net.0(ln))
+      a.out2 = reinterpret_cast<unsigned short*>(w.ff); a.out2_plane = R * 1024; a.ldo2 = 1024; a.out2_scale = b.ff2.a_scale;
+      JV_TRY(rowgemm(a, RG_GELU_PL, st));
+    } else {
+      // K = 256, N = 1024 with a GELU epilogue is where the tile kernel wins (traced 56 against 62 us): its 2-3 workgroups per
+      // CU run one's epilogue under another's main loop, which a one-workgroup-per-CU kernel cannot.  Same planes in and out.
+      ConvGemmArgs t = base_args(g, w.ln, 256, b.ff1, w.ff, 1024);
+      t.act = ACT_GELU;
+      h3(t, b.ff1);
+      planes_in(t, w.ln, 256);
+      t.out2 = reinterpret_cast<unsigned short*>(w.ff); t.out2_plane = R * 1024; t.ldo2 = 1024; t.out2_scale = b.ff2.a_scale;
+      JV_TRY(conv_gemm(t, 1, st));
+    }
+    a = rg_args(w.ff, 1024, b.ff2);      // out = h + ff.net.2(ff); the next block's norm1 of it
+    a.out = out; a.ldo = ldo; a.res = h; a.ldr = 256;
+    rg_track(a);
+    if (next && out == h) {
+      a.out2 = reinterpret_cast<unsigned short*>(w.ln); a.out2_plane = R * 256; a.ldo2 = 256; a.out2_scale = next->qkv.a_scale;
+      a.ln_g = next->n1.g; a.ln_b = next->n1.b;
+      return rowgemm(a, RG_RES_LN, st);
+    }
+    return rowgemm(a, RG_RES, st);
+  };
+  // the four blocks of a stage; the last one may retarget its output (skip / concat buffer)
+  auto stage_blocks = [&](const BtbW* blk, float* h, float* last_out, int last_ldo) -> int {
+    bool all = use_rg;
+    for (int j = 0; j < EST_NBLK; ++j) all = all && rg_ok(blk[j]);
+    for (int j = 0; j < EST_NBLK; ++j) {
+      const bool last = j == EST_NBLK - 1;
+      if (all) JV_TRY(btb_rg(blk[j], last ? nullptr : &blk[j + 1], j > 0, h, last ? last_out : h, last ? last_ldo : 256));
+      else JV_TRY(btb(blk[j], h, last ? last_out : h, last ? last_ldo : 256));
+    }
+    return JV_OK;
+  };
 
   // down: resnet -> 4 blocks (result doubles as the skip) -> causal conv
   JV_TRY(resnet(0, w.xin, 320, w.h, 256));
-  for (int j = 0; j < EST_NBLK; ++j) JV_TRY(btb(e.blk[0][j], w.h, j == EST_NBLK - 1 ? skip : w.h, j == EST_NBLK - 1 ? 512 : 256));
+  JV_TRY(stage_blocks(e.blk[0], w.h, skip, 512));
   {
     ConvGemmArgs a = base_args(g, skip, 512, e.down_conv, w.h, 256);
     causal3(a);
@@ -279,14 +358,11 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   // mid x12; the last block writes straight into columns [0,256) of the concat buffer
   for (int i = 1; i <= EST_NMID; ++i) {
     JV_TRY(resnet(i, w.h, 256, w.h, 256));
-    for (int j = 0; j < EST_NBLK; ++j) {
-      const bool last = (i == EST_NMID) && (j == EST_NBLK - 1);
-      JV_TRY(btb(e.blk[i][j], w.h, last ? w.cat : w.h, last ? 512 : 256));
-    }
+    JV_TRY(stage_blocks(e.blk[i], w.h, i == EST_NMID ? w.cat : w.h, i == EST_NMID ? 512 : 256));
   }
   // up: resnet(cat[x, skip]) -> 4 blocks -> causal conv -> final block -> 1x1 projection
   JV_TRY(resnet(EST_NRES - 1, w.cat, 512, w.h, 256));
-  for (int j = 0; j < EST_NBLK; ++j) JV_TRY(btb(e.blk[EST_NRES - 1][j], w.h, w.h, 256));
+  JV_TRY(stage_blocks(e.blk[EST_NRES - 1], w.h, w.h, 256));
   {
     ConvGemmArgs a = base_args(g, w.h, 256, e.up_conv, w.h2, 256);
     causal3(a);

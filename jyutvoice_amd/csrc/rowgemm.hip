@@ -1,0 +1,85 @@
+// Host side of the row-owning fp16x3 GEMM (rowgemm_kernel.h): tile height choice and launch.
+#include "rowgemm_kernel.h"
+
+namespace jv {
+
+namespace {
+
+template <int RT, int EPI>
+int rg_launch2(const RowGemmArgs& a, hipStream_t st) {
+  static bool raised[64] = {};      // per device: the attribute belongs to the kernel's image on the current device
+  int dev = 0;
+  JV_HIP(hipGetDevice(&dev));
+  if (!raised[dev & 63]) {
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<RT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               rg_lds_bytes<RT>()));
+    raised[dev & 63] = true;
+  }
+  const bool prof = prof_on();
+  if (prof) prof_begin(st);
+  hipLaunchKernelGGL((rowgemm_kernel<RT, EPI>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rg_lds_bytes<RT>(), st, a);
+  if (prof) {
+    static const std::string name = std::string("rowgemm_h3<") + std::to_string(16 * RT) + "x256" +
+                                    (EPI == RG_GELU_PL ? ",gelu" : EPI == RG_RES ? ",res" : EPI == RG_RES_LN ? ",res,ln" : "") + ">";
+    const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M);
+    const double bytes = 4.0 * (rows * a.K + (double)a.N * a.K + rows * a.N * ((EPI == RG_RES || EPI == RG_RES_LN) ? 2 : 1) +
+                                (EPI == RG_RES_LN ? rows * 256 : 0));
+    prof_end(st, name.c_str(), 2.0 * rows * a.N * a.K, bytes);
+  }
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+template <int RT>
+int rg_launch1(const RowGemmArgs& a, int epi, hipStream_t st) {
+  switch (epi) {
+    case RG_PLAIN: return rg_launch2<RT, RG_PLAIN>(a, st);
+    case RG_GELU_PL: return rg_launch2<RT, RG_GELU_PL>(a, st);
+    case RG_RES: return rg_launch2<RT, RG_RES>(a, st);
+    case RG_RES_LN: return rg_launch2<RT, RG_RES_LN>(a, st);
+    default: return fail(JV_ERR_ARG, "rowgemm: unknown epilogue");
+  }
+}
+
+}  // namespace
+
+// tile height (in 16-row units) for M rows: the fewest rounds of workgroups over the 256 CUs times the rows each round
+// costs; ties go to the taller tile (each weight byte is then used for more rows).  0: too few rows for one workgroup per
+// CU to pay (the tile kernels split N as well and keep more CUs busy).
+int rowgemm_tile(int M) {
+  if (const char* f = dyn_env("JV_ROWGEMM_RT")) return atoi(f);
+  int best = 0;
+  long best_cost = 0;
+  for (int rt = 2; rt <= 5; ++rt) {
+    const long wgs = cdiv(M, 16 * rt);
+    const long cost = cdivl(wgs, 256) * rt;
+    if (!best || cost < best_cost || (cost == best_cost && rt > best)) { best = rt; best_cost = cost; }
+  }
+  if (cdiv(M, 16 * best) < 96) return 0;
+  return best;
+}
+
+int rowgemm(const RowGemmArgs& a, int epi, hipStream_t st) {
+  if (a.M <= 0) return JV_OK;
+  if (const char* ab = tuning_env("JV_RG_ABLATE")) const_cast<RowGemmArgs&>(a).ablate = atoi(ab);
+  if (!a.A2 || !a.W2 || !a.colscale || !(a.a_scale > 0.f)) return fail(JV_ERR_ARG, "rowgemm: needs A and W planes, colscale and a_scale");
+  if ((a.K & 31) || a.K < 32 || (a.N & 255) || a.N < 256) return fail(JV_ERR_ARG, "rowgemm: K % 32 == 0 and N % 256 == 0 required");
+  if ((a.lda2 & 7) || (a.ldw & 7)) return fail(JV_ERR_ARG, "rowgemm: lda2 / ldw must be multiples of 8 halves");
+  if ((epi == RG_RES || epi == RG_RES_LN) && (a.N != 256 || !a.res || !a.out || (a.ldo & 3) || (a.ldr & 3)))
+    return fail(JV_ERR_ARG, "rowgemm: the residual epilogues own whole 256-wide rows");
+  if (epi == RG_PLAIN && (!a.out || (a.ldo & 3))) return fail(JV_ERR_ARG, "rowgemm: bad output");
+  if ((epi == RG_GELU_PL || epi == RG_RES_LN) && (!a.out2 || (a.ldo2 & 3))) return fail(JV_ERR_ARG, "rowgemm: bad plane output");
+  if (epi == RG_RES_LN && (!a.ln_g || !a.ln_b)) return fail(JV_ERR_ARG, "rowgemm: LayerNorm epilogue needs gain and offset");
+  int rt = rowgemm_tile(a.M);
+  if (rt == 0) rt = 2;      // callers ask rowgemm_tile() first; a direct call still works
+  switch (rt) {
+    case 1:
+    case 2: return rg_launch1<2>(a, epi, st);
+    case 3: return rg_launch1<3>(a, epi, st);
+    case 4: return rg_launch1<4>(a, epi, st);
+    case 5: return rg_launch1<5>(a, epi, st);
+    default: return fail(JV_ERR_ARG, "rowgemm: bad tile height");
+  }
+}
+
+}  // namespace jv

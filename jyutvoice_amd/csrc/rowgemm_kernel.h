@@ -1,0 +1,377 @@
+// Row-owning fp16x3 GEMM for the estimator's transformer linears (jyutvoice/flow/transformer.py:355-443: attn1.to_out.0,
+// ff.net.0.proj, ff.net.2, and the fused to_q/to_k/to_v), built for the shape that dominates the path: M ~ 19.5 K rows
+// (2 B utterances x (T + 4) frames), K = 256 ... 1024, N = 256 ... 1536.
+//
+// Why another GEMM.  The tile kernels (conv_gemm_x6_kernel.h) cut M x N into 64x64 ... 160x128 tiles.  For the N = 256
+// linears that left 1220 small tiles, each pulling 16 KB through its CU's load path per 24 MFMAs (A re-staged by every
+// column tile, 0.125 B per multiply-add): round 1's PMC put the matrix pipe at 25 % with the waves waiting on staging.
+// Here ONE 8-wave workgroup per CU owns R = 16 RT whole rows (RT = 5: 80 rows -> 244 workgroups for 19.5 K rows, one
+// round on 256 CUs) and all N columns, 256 at a time:
+//   * both operands arrive as fp16 planes by LDS-DMA (global_load_lds_dwordx4) into a 3-stage ring -- the producers
+//     (LayerNorm, attention, this kernel's own epilogues) write the A planes, so the main loop has no VALU work at all;
+//     waits are counted (s_waitcnt vmcnt(n)) and the one barrier per 32-deep K step is a bare s_barrier, so two steps
+//     of DMA stay in flight across it;
+//   * v_mfma_f32_16x16x32_f16: 16-row granularity is what lets 80-row tiles exist (32x32 tiles would mean 64 or 96 rows:
+//     304 or 203 workgroups), and the 16x16 shape holds a higher clock under load (MI355X_MICROARCH.md);
+//   * bytes per multiply-add: (1/256 + 1/80) x 4 B = 0.066, half the 64x64 tile's;
+//   * the workgroup owns whole rows, so what follows the GEMM row-wise runs in its epilogue: bias, residual, the NEXT
+//     LayerNorm (its result written as the next GEMM's pre-split operand), exact GELU, the measured-bound tracking.
+// Precision: identical arithmetic to the tile kernels' fp16x3 (three products hh' + hl' + lh' of the 2-plane splits of
+// A * a_scale and W * 2^e_n, fp32 accumulate, K in ascending 32-chunks): the same bits for the same operands.
+#pragma once
+#include <math.h>
+
+#include <string>
+#include <type_traits>
+
+#include "jv_common.h"
+#include "jv_device.h"
+
+namespace jv {
+
+typedef _Float16 rg_f16x8 __attribute__((ext_vector_type(8)));
+typedef float rg_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int rg_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int rg_u32x2 __attribute__((ext_vector_type(2)));
+
+enum RowGemmEpi : int {
+  RG_PLAIN = 0,      // out = acc * colscale / a_scale (+ bias): fp32 rows
+  RG_GELU_PL = 1,    // gelu(...) written as fp16 planes of value * out2_scale (ff.net.0 -> ff.net.2's operand)
+  RG_RES = 2,        // ... + res -> fp32 rows (+ amax tracking)
+  RG_RES_LN = 3,     // ... + res -> fp32 rows, then LayerNorm_256 of the row -> fp16 planes * ln_scale (the next GEMM's operand)
+};
+
+struct RowGemmArgs {
+  // A * a_scale as two fp16 planes [2][a_rows][lda2] (rows past a_rows - 1 are clamped: their outputs are never stored)
+  const unsigned short* A2;
+  long a2_plane, a_rows;
+  int lda2;
+  int M, K, N;      // K % 32 == 0, N % 256 == 0
+  // W[n][:] * 2^e_n as two fp16 planes [2][n_rows][ldw], colscale[n] = 2^-e_n (registry.hip `half3`)
+  const unsigned short* W2;
+  long w2_plane;
+  int ldw;
+  const float* colscale;
+  float a_scale;      // the power of two A was scaled with (a load-time bound, GemmW::a_scale)
+  const float* bias;  // [N] or null
+  float* out;         // RG_PLAIN / RG_RES / RG_RES_LN
+  long ldo;
+  const float* res;   // RG_RES / RG_RES_LN (may alias out)
+  long ldr;
+  unsigned short* out2;      // RG_GELU_PL: [2][rows][ldo2];  RG_RES_LN: the LayerNorm planes [2][rows][256]
+  long out2_plane;
+  int ldo2;
+  float out2_scale;
+  const float *ln_g, *ln_b;
+  float ln_eps;
+  // measured-bound tracking of what RG_RES / RG_RES_LN store (ConvGemmArgs::amax_out): slot = row_slot[m], rows with
+  // row_mask[m] == 0 are padding and not tracked
+  float* amax_out;
+  const int* row_slot;
+  const unsigned char* row_mask;
+  long alg_rows;      // profiler: real frames
+  int ablate;         // tuning aid (JV_RG_ABLATE, tuning builds): 1 no DMA in the loop, 2 no LDS reads + MFMAs, 4 no barrier/wait
+};
+
+constexpr int RG_SLD = 260;                      // slab row stride in floats (256 + 4: conflict-free b32 writes, aligned b128 reads)
+constexpr int RG_SLAB_ROWS = 32;
+constexpr int RG_SLAB_BYTES = RG_SLAB_ROWS * RG_SLD * 4;
+template <int RT> constexpr int rg_stage_bytes() { return 2 * 16 * RT * 64 + 2 * 256 * 64; }
+template <int RT> constexpr int rg_lds_bytes() { return 3 * rg_stage_bytes<RT>() + RG_SLAB_BYTES; }
+
+// 16-byte slot key of a row inside its 16-row group: with 64-byte rows (32 fp16), lane l of a 16x16x32 fragment read
+// takes row l & 15, k-slot l >> 4; XOR-ing bit 1 of the slot with bit 2 of the row puts the 16 lanes of every
+// ds_read_b128 lane group on 16 distinct 16-byte bank slots (brute-forced over the four lane groups of MI355X_MICROARCH.md)
+__device__ __forceinline__ int rg_key(int r) { return ((r >> 2) & 1) << 1; }
+
+template <int N>
+__device__ __forceinline__ void rg_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// Bare barriers (the "memory" clobber keeps the compiler from moving LDS / global accesses across them; s_barrier itself
+// waits for no counter).  __syncthreads() would add s_waitcnt vmcnt(0): in the main loop that drains the two steps of
+// LDS-DMA kept in flight, in the epilogue it waits for the row stores to be acknowledged.
+__device__ __forceinline__ void rg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+__device__ __forceinline__ void rg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int RT, int EPI>
+__global__ __launch_bounds__(512, 2) void rowgemm_kernel(const RowGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rg_lds[];
+  constexpr int R = 16 * RT;
+  constexpr int STAGE = rg_stage_bytes<RT>();
+  constexpr int A_PLANE = R * 64, W_PLANE = 256 * 64, W_OFF = 2 * A_PLANE;
+  constexpr int NPIECE = 2 * RT + 32;            // 1 KiB DMA pieces per stage: RT per A plane, 16 per W plane
+  constexpr int PPW = (NPIECE + 7) / 8;          // issued per wave and step, at most
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * R;
+  const int KS = p.K >> 5, NC = p.N >> 8;
+  const int total = KS * NC;
+  float* const slab = reinterpret_cast<float*>(rg_lds + 3 * STAGE);
+
+  // ---- warm this XCD's L2 with the weight planes.  Every workgroup streams ALL of W, a new 32 KB tile per step that no
+  // CU reads twice; in the estimator each launch has its own weights, cold in every cache, and with two steps (84 KB) in
+  // flight per CU the loop then runs at 84 KB per HBM latency (traced: 25 % slower than the same kernel on L2-hot weights).
+  // The workgroups that share an XCD (blockIdx % 8 under round-robin placement: a speed-only guess) each touch a slice of W
+  // once, 128 bytes apart, so the whole matrix is on its way into that L2 while the first steps run.
+  float warm = 0.f;
+  {
+    const long lpp = ((long)p.N * p.ldw * 2) >> 7;                 // 128-byte lines per plane
+    const int grp = blockIdx.x >> 3, ngrp = (gridDim.x + 7) >> 3;
+    const long per = (2 * lpp + ngrp - 1) / ngrp;
+    const long l = (long)grp * per + tid;
+    if (tid < per && l < 2 * lpp) {
+      const int pl = l >= lpp;
+      warm = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.W2 + (long)pl * p.w2_plane) + ((l - pl * lpp) << 7));
+    }
+    // (per <= 512 for every estimator shape at >= 96 workgroups; a larger W is simply warmed in part)
+  }
+
+  // ---- this wave's DMA pieces: per-lane source pointer at (chunk 0, k 0), wave-uniform LDS offset, per-chunk advance ----
+  const unsigned short* src[PPW];
+  int dst[PPW];
+  long cadv[PPW];
+  {
+    const int prow = lane >> 2, pslot = (lane & 3) ^ rg_key(prow);      // the DMA writes lane-linear: swizzle the SOURCE k-slot
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave + 8 * i;
+      if (pc < 2 * RT) {
+        const int pl = pc / RT, g = pc % RT;
+        long row = (long)m0 + g * 16 + prow;
+        row = row < p.a_rows ? row : p.a_rows - 1;
+        src[i] = p.A2 + (long)pl * p.a2_plane + row * p.lda2 + 8 * pslot;
+        dst[i] = pl * A_PLANE + g * 1024;
+        cadv[i] = 0;
+      } else {
+        const int q = pc - 2 * RT, pl = (q >> 4) & 1, g = q & 15;
+        src[i] = p.W2 + (long)pl * p.w2_plane + (long)(g * 16 + prow) * p.ldw + 8 * pslot;
+        dst[i] = W_OFF + pl * W_PLANE + g * 1024;
+        cadv[i] = 256L * p.ldw;
+      }
+    }
+  }
+  const int my_pieces = (NPIECE - wave + 7) / 8;      // pieces this wave really issues per step (wave-uniform)
+  // The pieces of one step are issued ONE AT A TIME between the step's MFMA groups, not in a burst behind the barrier:
+  // an LDS-DMA issue holds its wave for ~100 cycles, and in a burst both waves of a SIMD sit in theirs together while the
+  // matrix pipe idles (ablation: the loop took 33 us where DMA alone and MFMA alone took 20 and 21).  `cur[i]` walks the
+  // (chunk, k) sequence incrementally: + 32 halves per step, + cadv - K at a chunk boundary.
+  const unsigned short* cur[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) cur[i] = src[i];
+  int ik = 0;      // k-step of the next step to issue
+  auto issue_piece = [&](auto itag, int stage) {
+    constexpr int i = decltype(itag)::value;
+    if (wave + 8 * i < NPIECE) {      // wave-uniform
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)cur[i],
+                                       (__attribute__((address_space(3))) void*)(rg_lds + stage * STAGE + dst[i]), 16, 0, 0);
+    }
+  };
+  auto advance = [&]() {      // after all pieces of a step have been issued
+    const bool wrap = ++ik == KS;
+    if (wrap) ik = 0;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) cur[i] += wrap ? cadv[i] - p.K + 32 : 32;
+  };
+  auto issue_all = [&](int stage) {
+    issue_piece(std::integral_constant<int, 0>{}, stage);
+    if constexpr (PPW > 1) issue_piece(std::integral_constant<int, 1>{}, stage);
+    if constexpr (PPW > 2) issue_piece(std::integral_constant<int, 2>{}, stage);
+    if constexpr (PPW > 3) issue_piece(std::integral_constant<int, 3>{}, stage);
+    if constexpr (PPW > 4) issue_piece(std::integral_constant<int, 4>{}, stage);
+    if constexpr (PPW > 5) issue_piece(std::integral_constant<int, 5>{}, stage);
+    advance();
+  };
+  // all but this wave's `keep` youngest pieces have landed (keep = one step's worth, or 0)
+  auto wait_landed = [&](bool next_in_flight) {
+    if (!next_in_flight) {
+      rg_wait_vmcnt<0>();
+    } else if (my_pieces == PPW) {
+      rg_wait_vmcnt<PPW>();
+    } else {
+      rg_wait_vmcnt<PPW - 1>();
+    }
+  };
+
+  // per-lane fragment addresses inside a stage
+  const int fslot = (kq ^ rg_key(r16)) << 4;
+  const int a_off = r16 * 64 + fslot;                                   // + pl * A_PLANE + mt * 1024
+  const int w_off = W_OFF + (wave * 32 + r16) * 64 + fslot;             // + pl * W_PLANE + nt * 1024
+
+  rg_f32x4 acc[RT][2];
+  issue_all(0);
+  if (total > 1) issue_all(1);
+  int s = 0;
+  for (int c = 0; c < NC; ++c) {
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < KS; ++ks, ++s) {
+      // step s's pieces: mine have landed (all but the younger step's), then everyone's have -- and every wave is done
+      // reading the stage that step s + 2 will overwrite (it was read in step s - 1)
+      if (!JV_ABLATE(p, 4)) {
+        wait_landed(s + 1 < total);
+        rg_barrier();
+      }
+      const bool more = s + 2 < total && !JV_ABLATE(p, 1);
+      const int nstage = (s + 2) % 3;
+      if (JV_ABLATE(p, 2)) {
+        if (more) issue_all(nstage);
+        continue;
+      }
+      const unsigned char* const st = rg_lds + (s % 3) * STAGE;
+      rg_u32x4 b[2][2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) b[nt][pl] = *reinterpret_cast<const rg_u32x4*>(st + w_off + pl * W_PLANE + nt * 1024);
+      auto group = [&](auto mtag) {
+        constexpr int mt = decltype(mtag)::value;
+        rg_u32x4 a[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) a[pl] = *reinterpret_cast<const rg_u32x4*>(st + a_off + pl * A_PLANE + mt * 1024);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          rg_f32x4 t = acc[mt][nt];
+          auto mm = [&](const rg_u32x4& x, const rg_u32x4& y) {
+            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rg_f16x8, x), __builtin_bit_cast(rg_f16x8, y), t, 0, 0, 0);
+          };
+          mm(a[1], b[nt][0]);      // smallest terms first, as the tile kernels do
+          mm(a[0], b[nt][1]);
+          mm(a[0], b[nt][0]);
+          acc[mt][nt] = t;
+        }
+        // this group's share of the next-but-one step's DMA: pieces mt, mt + RT, ... of the wave's list
+        if (more) {
+          issue_piece(std::integral_constant<int, mt>{}, nstage);
+          if constexpr (mt + RT < PPW) issue_piece(std::integral_constant<int, (mt + RT < PPW ? mt + RT : 0)>{}, nstage);
+          if constexpr (mt + 2 * RT < PPW) issue_piece(std::integral_constant<int, (mt + 2 * RT < PPW ? mt + 2 * RT : 0)>{}, nstage);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the interleave: the scheduler would hoist the DMA issues together
+      };
+      group(std::integral_constant<int, 0>{});
+      if constexpr (RT > 1) group(std::integral_constant<int, 1>{});
+      if constexpr (RT > 2) group(std::integral_constant<int, 2>{});
+      if constexpr (RT > 3) group(std::integral_constant<int, 3>{});
+      if constexpr (RT > 4) group(std::integral_constant<int, 4>{});
+      if (more) advance();
+    }
+
+    // ---- epilogue of chunk c: 32 rows at a time through the slab (its own LDS region: the ring keeps streaming) ----
+    const int n0 = c * 256 + 4 * lane;      // this lane's four columns in the row pass
+    rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.colscale + n0);
+    cs4 = cs4 * (1.0f / p.a_scale);        // powers of two: exact
+    rg_f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) b4 = *reinterpret_cast<const rg_f32x4*>(p.bias + n0);
+#pragma unroll
+    for (int ps = 0; ps < (RT + 1) / 2; ++ps) {
+#pragma unroll
+      for (int ml = 0; ml < 2; ++ml) {
+        if (2 * ps + ml < RT) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              slab[(ml * 16 + kq * 4 + e) * RG_SLD + wave * 32 + nt * 16 + r16] = acc[2 * ps + ml][nt][e];
+        }
+      }
+      rg_lds_barrier();
+      constexpr int RPW = RG_SLAB_ROWS / 8;      // rows per wave and pass
+      rg_f32x4 v[RPW];
+      long mrow[RPW];
+      bool ok[RPW];
+#pragma unroll
+      for (int j = 0; j < RPW; ++j) {
+        const int trow = ps * 32 + wave * RPW + j;
+        mrow[j] = (long)m0 + trow;
+        ok[j] = trow < R && mrow[j] < p.M;
+        v[j] = *reinterpret_cast<const rg_f32x4*>(slab + (wave * RPW + j) * RG_SLD + 4 * lane) * cs4 + b4;
+      }
+      if constexpr (EPI == RG_PLAIN) {
+#pragma unroll
+        for (int j = 0; j < RPW; ++j)
+          if (ok[j]) *reinterpret_cast<rg_f32x4*>(p.out + mrow[j] * p.ldo + n0) = v[j];
+      } else if constexpr (EPI == RG_GELU_PL) {
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+          if (!ok[j]) continue;
+          rg_f32x4 t = v[j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = gelu_erf(t[e]);
+          const Split2 s0 = split2h_pair(t[0] * p.out2_scale, t[1] * p.out2_scale);
+          const Split2 s1 = split2h_pair(t[2] * p.out2_scale, t[3] * p.out2_scale);
+          unsigned short* o2 = p.out2 + mrow[j] * p.ldo2 + n0;
+          *reinterpret_cast<rg_u32x2*>(o2) = rg_u32x2{s0.h, s1.h};
+          *reinterpret_cast<rg_u32x2*>(o2 + p.out2_plane) = rg_u32x2{s0.l, s1.l};
+        }
+      } else {
+        // + residual -> fp32 rows (+ tracking) (-> LayerNorm -> planes)
+        rg_f32x4 r[RPW];
+        unsigned seen[RPW];
+        bool tracked[RPW];
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+          r[j] = ok[j] ? *reinterpret_cast<const rg_f32x4*>(p.res + mrow[j] * p.ldr + 4 * lane) : rg_f32x4{0.f, 0.f, 0.f, 0.f};
+          tracked[j] = false;
+          seen[j] = 0xffffffffu;
+          if (p.amax_out && ok[j]) {
+            tracked[j] = !p.row_mask || p.row_mask[mrow[j]] != 0;
+            // (a plain, cacheable load: the slot only grows, so a stale value is a valid lower bound)
+            seen[j] = *reinterpret_cast<const unsigned*>(p.amax_out + (p.row_slot ? p.row_slot[mrow[j]] : 0));
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+          v[j] += r[j];
+          if (ok[j]) *reinterpret_cast<rg_f32x4*>(p.out + mrow[j] * p.ldo + 4 * lane) = v[j];
+        }
+        if (p.amax_out) {
+#pragma unroll
+          for (int j = 0; j < RPW; ++j) {
+            unsigned u = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u = max(u, __float_as_uint(v[j][e]) & 0x7fffffffu);
+            // wave-uniform branch (a wave holds whole rows): nothing to do once the slot holds a larger value
+            if (tracked[j] && __builtin_amdgcn_ballot_w64(u > seen[j]) != 0) {
+#pragma unroll
+              for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o));
+              if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(p.amax_out + (p.row_slot ? p.row_slot[mrow[j]] : 0)), u);
+            }
+          }
+        }
+        if constexpr (EPI == RG_RES_LN) {
+          // LayerNorm over the row's 256 channels (two-pass, as rowops.hip's layernorm256_kernel), written as the next
+          // GEMM's pre-split operand
+          const rg_f32x4 gg = *reinterpret_cast<const rg_f32x4*>(p.ln_g + 4 * lane);
+          const rg_f32x4 bb = *reinterpret_cast<const rg_f32x4*>(p.ln_b + 4 * lane);
+          float sum[RPW], sq[RPW];
+#pragma unroll
+          for (int j = 0; j < RPW; ++j) sum[j] = wave_sum((v[j][0] + v[j][1]) + (v[j][2] + v[j][3]));
+#pragma unroll
+          for (int j = 0; j < RPW; ++j) {
+            const rg_f32x4 d = v[j] - sum[j] * (1.f / 256.f);
+            sq[j] = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+          }
+#pragma unroll
+          for (int j = 0; j < RPW; ++j) {
+            if (!ok[j]) continue;
+            const float mean = sum[j] * (1.f / 256.f);
+            const float rstd = 1.0f / sqrtf(sq[j] * (1.f / 256.f) + p.ln_eps);
+            const rg_f32x4 y = (v[j] - mean) * rstd * gg + bb;
+            const Split2 s0 = split2h_pair(y[0] * p.out2_scale, y[1] * p.out2_scale);
+            const Split2 s1 = split2h_pair(y[2] * p.out2_scale, y[3] * p.out2_scale);
+            unsigned short* o2 = p.out2 + mrow[j] * p.ldo2 + 4 * lane;
+            *reinterpret_cast<rg_u32x2*>(o2) = rg_u32x2{s0.h, s1.h};
+            *reinterpret_cast<rg_u32x2*>(o2 + p.out2_plane) = rg_u32x2{s0.l, s1.l};
+          }
+        }
+      }
+      rg_lds_barrier();      // the slab is rewritten by the next pass / chunk
+    }
+  }
+  asm volatile("" ::"v"(warm));      // the warm-up load is waited for here, not before
+}
+
+}  // namespace jv

@@ -281,6 +281,28 @@ def op_attention_h3(qkv, lens, B, G, S, L, bounds=None):
     return out
 
 
+def op_rowgemm(A, W, bias=None, epi="plain", res=None, ln=None, a_bound=None, out2_scale=1.0, presplit=0, amax_out=None):
+    """the row-owning fp16x3 GEMM (rowgemm_kernel.h): returns out fp32 [M,N] (plain / res), the fp16 planes as an fp32
+    tensor h + l (gelu), or (out, planes) for res+ln.  Planes come back un-scaled (divided by out2_scale)."""
+    lib = _lib.load()
+    rows, K = A.shape
+    N = W.shape[0]
+    code = {"plain": 0, "gelu": 1, "res": 2, "res_ln": 3}[epi]
+    bound = float(A.abs().max()) if a_bound is None else float(a_bound)
+    out = torch.empty(rows, N, device=A.device) if code != 1 else None
+    pc = 256 if code == 3 else N
+    out2 = torch.empty(2, rows, pc, dtype=torch.float16, device=A.device) if code in (1, 3) else None
+    g, b = (ln if ln is not None else (None, None))
+    check(lib.jv_op_rowgemm(_ptr(A), rows, rows, K, _ptr(W), N, _ptr(bias), code, _ptr(res), _ptr(g), _ptr(b), bound,
+                            float(out2_scale), int(presplit), _ptr(out), _ptr(out2), _ptr(amax_out), _stream(A.device)))
+    if presplit == 2:      # timing call: no post-processing
+        return out
+    planes = None if out2 is None else (out2[0].double() + out2[1].double()) / out2_scale
+    if code == 1:
+        return planes
+    return (out, planes) if code == 3 else out
+
+
 def op_layernorm(x, g, b, eps=1e-5):
     lib = _lib.load()
     out = torch.empty_like(x)

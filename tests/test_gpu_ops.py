@@ -456,3 +456,60 @@ def test_h3_measured_bound_not_finite(dev):
     slot = torch.zeros(1, device=dev)
     op_conv_h3_measured(A2, W, None, amax_out=slot)
     assert not torch.isfinite(slot).all()
+
+
+# ---- row-owning fp16x3 GEMM (rowgemm_kernel.h): the estimator's transformer linears at chip-filling batch sizes --------
+@pytest.mark.parametrize("rt", ["2", "3", "4", "5"])
+@pytest.mark.parametrize("K,N", [(512, 256), (256, 1024), (64, 512)])
+def test_rowgemm_plain_every_tile_height(dev, monkeypatch, rt, K, N):
+    """fp32-level accuracy against fp64 on ragged row counts (last workgroup partly empty), every tile height, one and
+    several 256-column chunks, K of one to sixteen steps; and the same result as the tile kernels' fp16x3 on the same operands
+    up to the summation order inside an MFMA (16x16x32 here, 32x32x16 there)"""
+    from jyutvoice_amd.engine import op_linear_h3, op_rowgemm
+    monkeypatch.setenv("JV_ROWGEMM_RT", rt)
+    g = torch.Generator().manual_seed(int(rt) * 1000 + K + N)
+    M = 1000 + 7 * int(rt)
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    out = op_rowgemm(A, W, b, a_bound=8.0)
+    want = A.double().cpu() @ W.double().cpu().T + b.double().cpu()
+    assert rel_err(out, want) < 2e-6
+    assert rel_err(out, op_linear_h3(A, W, b, a_bound=8.0).double().cpu()) < 1e-6
+
+
+def test_rowgemm_epilogues(dev, monkeypatch):
+    """GELU -> planes, + residual (with the measured-bound tracking), + residual -> LayerNorm -> planes: each against fp64"""
+    from jyutvoice_amd.engine import op_rowgemm
+    g = torch.Generator().manual_seed(77)
+    M, K = 2100, 256
+    A = torch.randn(M, K, generator=g).to(dev)
+    W1 = (torch.randn(1024, K, generator=g) / math.sqrt(K)).to(dev)
+    b1 = torch.randn(1024, generator=g).to(dev)
+    Ad, W1d, b1d = A.double().cpu(), W1.double().cpu(), b1.double().cpu()
+    # exact GELU, written as the next GEMM's operand: h + l planes reproduce it to 22 bits
+    got = op_rowgemm(A, W1, b1, epi="gelu", a_bound=8.0, out2_scale=64.0).cpu()
+    want = F.gelu(Ad @ W1d.T + b1d)
+    assert float((got - want).abs().max()) < 2e-6 * float(want.abs().max())
+    # + residual, tracked maximum exact
+    W2 = (torch.randn(256, K, generator=g) / math.sqrt(K)).to(dev)
+    b2 = torch.randn(256, generator=g).to(dev)
+    res = torch.randn(M, 256, generator=g).to(dev)
+    slot = torch.zeros(1, device=dev)
+    out = op_rowgemm(A, W2, b2, epi="res", res=res, a_bound=8.0, amax_out=slot)
+    want = Ad @ W2.double().cpu().T + b2.double().cpu() + res.double().cpu()
+    assert rel_err(out, want) < 2e-6
+    assert float(slot) == float(out.abs().max())
+    # in place (res aliases out, as the estimator runs it) + LayerNorm of the new row -> planes
+    lg = (1 + 0.1 * torch.randn(256, generator=g)).to(dev)
+    lb = (0.02 * torch.randn(256, generator=g)).to(dev)
+    out, planes = op_rowgemm(A, W2, b2, epi="res_ln", res=res, ln=(lg, lb), a_bound=8.0, out2_scale=1024.0)
+    assert rel_err(out, want) < 2e-6
+    ln_want = F.layer_norm(want, (256,), lg.double().cpu(), lb.double().cpu(), 1e-5)
+    assert float((planes.cpu() - ln_want).abs().max()) < 5e-6
+    # the DMA ring under memory pressure: identical bits over repeated launches beside a streaming writer
+    first = op_rowgemm(A, W2, b2, epi="res", res=res, a_bound=8.0)
+    noise = torch.empty(64 << 20, device=dev)
+    for i in range(20):
+        noise.normal_()
+        assert torch.equal(op_rowgemm(A, W2, b2, epi="res", res=res, a_bound=8.0), first), i

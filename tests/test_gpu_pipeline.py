@@ -221,13 +221,21 @@ def test_full_size_batch_invariance(models):
         s = torch.randn(B, 1, 480 * 2 * Tt, device="cuda:0", generator=g) * 0.01
         wav = hift.decode(res["mel"], s)
         assert wav.shape == (B, 480 * 2 * Tt) and torch.isfinite(wav).all() and float(wav.abs().max()) <= 0.99 + 1e-6
+        # bit for bit across shardings: the measured fp16x3 bounds are per utterance (ConvGemmArgs::amax_G/S/nb) and a kernel
+        # sums a row in the same order wherever the row sits, so an utterance does not see its batch.  Two 16-utterance
+        # shards (what data parallelism over 2 GPUs runs) reproduce the 32-utterance result exactly ...
+        for lo in (0, 16):
+            half = tts.synthesise(*args(slice(lo, lo + 16)), n_timesteps=3, batched=True)
+            assert torch.equal(half["mel"], res["mel"][lo:lo + 16]), (lo, md(half["mel"], res["mel"][lo:lo + 16]))
+            assert torch.equal(hift.decode(half["mel"], s[lo:lo + 16]), wav[lo:lo + 16]), lo
+        # ... and a single utterance, whose transformer linears run on the tile kernels instead of the row-owning GEMM (too
+        # few rows to fill the chip: another MFMA shape, another summation order inside a product), agrees to rounding;
+        # the vocoder has one kernel set at every size and stays exact
         for i in (0, 17, 31):
             one = tts.synthesise(*args(slice(i, i + 1)), n_timesteps=3)
-            # bit for bit: the measured fp16x3 bounds are per utterance (ConvGemmArgs::amax_G/S/nb) and every tile variant
-            # sums in the same order, so an utterance does not see its batch (nor, therefore, how a batch is sharded)
-            assert torch.equal(one["mel"], res["mel"][i:i + 1]), (i, md(one["mel"], res["mel"][i:i + 1]))
-            assert torch.equal(hift._engine(1, 2 * Tt).hift_f0(one["mel"], None), f0[i:i + 1]), i
-            assert torch.equal(hift.decode(one["mel"], s[i:i + 1]), wav[i:i + 1]), i
+            assert md(one["mel"], res["mel"][i:i + 1]) <= 2e-5, i
+            assert md(hift._engine(1, 2 * Tt).hift_f0(one["mel"], None), f0[i:i + 1]) <= 1e-2
+            assert torch.equal(hift.decode(res["mel"][i:i + 1].clone(), s[i:i + 1]), wav[i:i + 1]), i
     finally:
         tts.load_state_dict(synth.tts_state_dict())
 

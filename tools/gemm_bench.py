@@ -15,7 +15,7 @@ os.environ.setdefault("JV_DYNAMIC_ENV", "1")
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from jyutvoice_amd.engine import op_attention, op_attention_h3, op_conv_gemm, op_linear_h3  # noqa: E402
+from jyutvoice_amd.engine import op_attention, op_attention_h3, op_conv_gemm, op_linear_h3, op_rowgemm  # noqa: E402
 
 dev = torch.device("cuda:0")
 M = int(os.environ.get("JV_M", 4 + 64 * 304))
@@ -49,7 +49,19 @@ for name, cin, n, taps, ln in shapes:
     if ln:
         kw["ln"] = (torch.ones(n, device=dev), torch.zeros(n, device=dev))
         kw["act"] = "mish"
-    if os.environ.get("JV_OP_H3") and taps == 1 and not ln:      # fp16x3 main loop (linears only)
+    if os.environ.get("JV_OP_ROWGEMM") and taps == 1 and not ln and n % 256 == 0:      # row-owning fp16x3 GEMM (rowgemm_kernel.h)
+        A = A[:M].contiguous()
+        epi = os.environ.get("JV_ROWGEMM_EPI", "plain")
+        kw2 = {}
+        if epi in ("res", "res_ln"):
+            if n != 256:
+                continue
+            kw2["res"] = torch.randn(M, n, generator=g).to(dev)
+        if epi == "res_ln":
+            kw2["ln"] = (torch.ones(n, device=dev), torch.zeros(n, device=dev))
+        op_rowgemm(A, W, b, epi=epi, a_bound=8.0, **kw2)
+        t = timeit(lambda: op_rowgemm(A, W, b, epi=epi, a_bound=8.0, presplit=2, **kw2))
+    elif os.environ.get("JV_OP_H3") and taps == 1 and not ln:      # fp16x3 main loop (linears only)
         A = A[:M].contiguous()
         if os.environ.get("JV_H3_DMA_A"):       # A pre-split into fp16 planes once, both operands by LDS-DMA
             op_linear_h3(A, W, b, a_bound=8.0, presplit=1)
