@@ -75,6 +75,12 @@ int jv_finalize(jv_context* ctx, int model, void* stream);
  * out may alias x (the TRT seam writes its result into x). */
 int jv_flow_estimator_step(jv_context* ctx, const float* x, const int32_t* lens, const float* mu, const float* t,
                            const float* spks, const float* cond, int B2, int T, float* out, void* stream);
+/* jv_flow_estimator_masked: the same call with the six named tensors of the TensorRT seam exactly as
+ * ConditionalCFM.forward_estimator binds them (flow_matching.py:270-290; profile shapes scripts/export_onnx.py:343-346):
+ * mask is the reference's own float mask [B2,1,T] (1 = frame, 0 = padding) instead of lengths; the result may be written
+ * into x (the seam passes x.data_ptr() as the output address).  jyutvoice_amd.flow.estimator.HipEstimator wraps it. */
+int jv_flow_estimator_masked(jv_context* ctx, const float* x, const float* mask, const float* mu, const float* t,
+                             const float* spks, const float* cond, int B2, int T, float* out, void* stream);
 /* jv_flow_set_streaming: the `streaming=True` mode of CausalConditionalDecoder.forward (decoder.py:951-954, 976-979,
  * 999-1002 -> utils/mask.py:91-126,192-198): chunk-causal attention with static_chunk_size = chunk_frames (50 in
  * configs/base.yaml:98) and all left chunks; 0 restores full attention.  Applies to the following estimator / solver

@@ -47,6 +47,7 @@ SIGNATURES = {
     "jv_load_noise": (_i, [_p, _p, _i64, _i, _p]),
     "jv_finalize": (_i, [_p, _i, _p]),
     "jv_flow_estimator_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
+    "jv_flow_estimator_masked": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
     "jv_flow_set_streaming": (_i, [_p, _i]),
     "jv_flow_set_graph": (_i, [_p, _i]),
     "jv_flow_set_contraction": (_i, [_p, _i]),

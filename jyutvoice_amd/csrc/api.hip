@@ -209,6 +209,13 @@ int jv_flow_estimator_step(jv_context* ctx, const float* x, const int32_t* lens,
   return jv::flow_estimator(ctx->c, x, lens, mu, t, spks, cond, B2, T, out, static_cast<hipStream_t>(stream));
 }
 
+int jv_flow_estimator_masked(jv_context* ctx, const float* x, const float* mask, const float* mu, const float* t,
+                             const float* spks, const float* cond, int B2, int T, float* out, void* stream) {
+  CTX_GUARD(ctx);
+  if (!x || !mask || !mu || !t || !spks || !cond || !out) return jv::fail(JV_ERR_ARG, "jv_flow_estimator_masked: null tensor");
+  return jv::flow_estimator(ctx->c, x, nullptr, mu, t, spks, cond, B2, T, out, static_cast<hipStream_t>(stream), mask);
+}
+
 int jv_flow_set_streaming(jv_context* ctx, int chunk_frames) {
   CTX_GUARD(ctx);
   if (chunk_frames < 0) return jv::fail(JV_ERR_ARG, "jv_flow_set_streaming: chunk must be >= 0");

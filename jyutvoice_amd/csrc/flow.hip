@@ -398,8 +398,18 @@ int check_shape(Context& c, int B2, int T) {
 // In a resnet whose input and output are the same buffer (mid blocks), block2 writes `out` only after
 // block1 and res_conv have consumed `in`; stream order makes that safe.
 
+// valid frames per row from the reference's float mask [B2,1,T] (1 = frame, 0 = padding; make_pad_mask gives prefixes)
+__global__ void mask_to_lens_kernel(const float* __restrict__ mask, int T, int* __restrict__ lens) {
+  const int b = blockIdx.x;
+  int n = 0;
+  for (int t = threadIdx.x; t < T; t += 64) n += mask[(long)b * T + t] != 0.f ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+  if (threadIdx.x == 0) lens[b] = n;
+}
+
 int flow_estimator(Context& c, const float* x, const int* lens_dev, const float* mu, const float* t_dev, const float* spks,
-                   const float* cond, int B2, int T, float* out, hipStream_t st) {
+                   const float* cond, int B2, int T, float* out, hipStream_t st, const float* mask_f32) {
   JV_TRY(check_shape(c, B2, T));
   FlowWs& w = *c.flow;
   Geo g{B2, T, T + FLOW_GAP, flow_rows(B2, T), w.rows_alloc, w.t_dev, 1};
@@ -407,7 +417,8 @@ int flow_estimator(Context& c, const float* x, const int* lens_dev, const float*
   JV_TRY(cf_to_rows(x, 80L * T, T, B2, 80, T, w.x, 80, 0, FLOW_G, g.S, 1.f, nullptr, st));
   JV_TRY(cf_to_rows(mu, 80L * T, T, B2, 80, T, w.mu, 80, 0, FLOW_G, g.S, 1.f, nullptr, st));
   JV_TRY(cf_to_rows(cond, 80L * T, T, B2, 80, T, w.cond, 80, 0, FLOW_G, g.S, 1.f, nullptr, st));
-  if (lens_dev) JV_HIP(hipMemcpyAsync(w.lens2, lens_dev, sizeof(int) * B2, hipMemcpyDeviceToDevice, st));
+  if (mask_f32) hipLaunchKernelGGL(mask_to_lens_kernel, dim3(B2), dim3(64), 0, st, mask_f32, T, w.lens2);
+  else if (lens_dev) JV_HIP(hipMemcpyAsync(w.lens2, lens_dev, sizeof(int) * B2, hipMemcpyDeviceToDevice, st));
   else JV_TRY(fill_int(w.lens2, T, B2, st));
   JV_TRY(row_meta(w.rowmask, w.row_sample, w.lens2, B2, 1, FLOW_G, g.S, T, w.rows_alloc, 1, 0, st));
   JV_HIP(hipMemcpyAsync(w.t_dev, t_dev, sizeof(float) * B2, hipMemcpyDeviceToDevice, st));

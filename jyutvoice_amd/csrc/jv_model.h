@@ -157,7 +157,7 @@ void flow_ws_forget_attention(Context& c, hipStream_t st);   // zero the attenti
 bool flow_has_graphs(const Context& c);
 void flow_graphs_drop(Context& c);   // forget captured Euler-step graphs (weights or workspace pointers changed)
 int flow_estimator(Context& c, const float* x, const int* lens_dev, const float* mu, const float* t_dev, const float* spks,
-                   const float* cond, int B2, int T, float* out, hipStream_t st);
+                   const float* cond, int B2, int T, float* out, hipStream_t st, const float* mask_f32 = nullptr);
 int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spks, const float* cond, int B, int T,
               int n_timesteps, float temperature, const float* t_span_host, float* mel, hipStream_t st);
 

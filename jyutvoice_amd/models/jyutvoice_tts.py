@@ -34,6 +34,8 @@ class JyutVoiceTTS:
         self.output_size = output_size
         self.freeze_encoder, self.freeze_decoder = freeze_encoder, freeze_decoder
         self.device = torch.device(device)
+        if hasattr(decoder, "device"):
+            decoder.device = self.device
         self._loaded = False
         self._sd: Dict[str, torch.Tensor] = {}
         self._missing = list(spec.TTS_INVENTORY)
@@ -43,6 +45,8 @@ class JyutVoiceTTS:
     # ---- nn.Module-shaped plumbing used by infer.py:341-346 -----------------------------------------
     def to(self, device):
         self.device = torch.device(device)
+        if hasattr(self.decoder, "device"):
+            self.decoder.device = self.device
         return self
 
     def eval(self):
