@@ -193,6 +193,11 @@ int jv_op_linear_h3(const float* A, int64_t rows, int M, int K, const float* W, 
 int jv_op_rowgemm(const float* A, int64_t rows, int M, int K, const float* W, int N, const float* bias, int epi,
                   const float* res, const float* ln_g, const float* ln_b, float a_bound, float out2_scale, int presplit,
                   float* out, uint16_t* out2, float* amax_out, void* stream);
+/* jv_op_attention_planes: the estimator's attention kernel at chip-filling batch sizes (attention_pl.hip: K / V taken as
+ * fp16 planes by LDS-DMA, transposed LDS reads for V) on an fp32 qkv matrix [rows,1536]; chunk > 0: chunk-causal mask;
+ * out2 != NULL: result as fp16 planes [2][rows][512] of value * out2_scale, else fp32 rows in out [rows,512]. */
+int jv_op_attention_planes(const float* qkv, int64_t rows, const int32_t* lens, int B, int G, int S, int L, float q_bound,
+                           float k_bound, float v_bound, int chunk, float out2_scale, float* out, uint16_t* out2, void* stream);
 int jv_op_layernorm(const float* x, const float* g, const float* b, float eps, int64_t rows, int C, float* out,
                     void* stream);
 

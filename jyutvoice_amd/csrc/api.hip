@@ -16,7 +16,8 @@ int rowgemm(const RowGemmArgs& a, int epi, hipStream_t st);   // rowgemm.hip
 int split3_planes(const float* src, unsigned short* dst, long n, hipStream_t st);   // registry.hip
 int split2h_planes(const float* src, int rows, int ld, float* stats, unsigned short* dst, float* colscale, hipStream_t st);
 float h3_scale_for_bound(float bound);
-int split2h_rows(const float* x, long ld, unsigned short* dst, long plane, long rows, int C, float scale, hipStream_t st);   // rowops.hip
+int split2h_rows(const float* x, long ld, unsigned short* dst, long plane, long rows, int C, float scale, hipStream_t st,
+                 long ldd = 0);   // rowops.hip
 
 static thread_local std::string g_last_error;
 
@@ -98,6 +99,7 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   c.dma_a = getenv("JV_DMA_A") != nullptr;
   c.no_rowgemm = getenv("JV_NO_ROWGEMM") != nullptr;
   c.rg_ff1 = getenv("JV_RG_FF1") != nullptr;
+  c.no_attn_planes = getenv("JV_NO_ATTN_PLANES") != nullptr;
   c.max_frames = max_frames;
   c.max_tokens = max_tokens;
   jv::build_registry(c);
@@ -438,6 +440,34 @@ int jv_op_rowgemm(const float* A, int64_t rows, int M, int K, const float* W, in
   a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
   a.amax_out = amax_out;
   return jv::rowgemm(a, epi, st);
+}
+
+// attention64_planes (attention_pl.hip) on an fp32 qkv matrix: K and V are split into planes here the way the qkv GEMM's
+// epilogue writes them; planes_out = 1: the result as fp16 planes [2][rows][512] of value * out2_scale (test hook)
+int jv_op_attention_planes(const float* qkv, int64_t rows, const int32_t* lens, int B, int G, int S, int L, float q_bound,
+                           float k_bound, float v_bound, int chunk, float out2_scale, float* out, uint16_t* out2, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static unsigned short* kv = nullptr;
+  static size_t cap = 0;
+  const size_t need = (size_t)rows * 1024 * 2 * sizeof(unsigned short);
+  if (need > cap) {
+    if (kv) (void)hipFree(kv);
+    JV_HIP(hipMalloc(reinterpret_cast<void**>(&kv), need));
+    cap = need;
+  }
+  jv::AttnArgs at{};
+  at.qkv = qkv; at.ld = 1536; at.out = out; at.ldo = 512;
+  at.B = B; at.H = 8; at.G = G; at.S = S; at.L = L; at.lens = lens; at.chunk = chunk;
+  at.q_scale = jv::h3_scale_for_bound(q_bound * 0.1803369f);
+  at.k_scale = jv::h3_scale_for_bound(k_bound);
+  at.v_scale = jv::h3_scale_for_bound(v_bound);
+  if (!(at.q_scale > 0.f && at.k_scale > 0.f && at.v_scale > 0.f)) return jv::fail(JV_ERR_ARG, "jv_op_attention_planes: unusable bound");
+  const long plane = (long)rows * 1024;
+  JV_TRY(jv::split2h_rows(qkv + 512, 1536, kv, plane, rows, 512, at.k_scale, st, 1024));
+  JV_TRY(jv::split2h_rows(qkv + 1024, 1536, kv + 512, plane, rows, 512, at.v_scale, st, 1024));
+  at.kv2 = kv; at.kv2_plane = plane; at.kv_ld = 1024;
+  if (out2) { at.out2 = out2; at.out2_plane = (long)rows * 512; at.out2_scale = out2_scale; }
+  return jv::attention64_planes(at, st);
 }
 
 int jv_op_layernorm(const float* x, const float* g, const float* b, float eps, int64_t rows, int C, float* out, void* stream) {

@@ -293,16 +293,28 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   };
   auto btb_rg = [&](const BtbW& b, const BtbW* next, bool ln_ready, float* h, float* out, int ldo) -> int {
     if (!ln_ready) JV_TRY(layernorm256_planes(h, reinterpret_cast<unsigned short*>(w.ln), R * 256, b.qkv.a_scale, b.n1.g, b.n1.b, 1e-5f, g.M, st));
+    // q | k | v = to_q/k/v(ln): q as fp32 rows [R,512] at the head of the qkv buffer, k and v as fp16 planes [2][R][1024]
+    // behind it (same bytes as [R,1536] fp32), scaled for the attention kernel, which then splits nothing
     RowGemmArgs a = rg_args(w.ln, 256, b.qkv);
-    a.out = w.qkv; a.ldo = 1536;
-    JV_TRY(rowgemm(a, RG_PLAIN, st));
+    unsigned short* const kv2 = reinterpret_cast<unsigned short*>(w.qkv + R * 512);
     AttnArgs at{};
-    at.qkv = w.qkv; at.ld = 1536; at.k_off = 512; at.v_off = 1024; at.out = w.att; at.ldo = 512;
+    at.qkv = w.qkv; at.out = w.att; at.ldo = 512;
     at.B = B2; at.H = EST_HEADS; at.G = FLOW_G; at.S = g.S; at.L = g.T; at.lens = w.lens2;
     at.chunk = c.attn_chunk;
     at.q_scale = b.q_scale; at.k_scale = b.k_scale; at.v_scale = b.v_scale;
     at.out2 = reinterpret_cast<unsigned short*>(w.att); at.out2_plane = R * 512; at.out2_scale = b.out.a_scale;
-    JV_TRY(attention64(at, st));
+    if (!c.no_attn_planes) {
+      a.out = w.qkv; a.ldo = 512;
+      a.out2 = kv2; a.out2_plane = R * 1024; a.ldo2 = 1024; a.out2_scale = b.k_scale; a.out2_scale2 = b.v_scale;
+      JV_TRY(rowgemm(a, RG_QKV, st));
+      at.ld = 512; at.kv2 = kv2; at.kv2_plane = R * 1024; at.kv_ld = 1024;
+      JV_TRY(attention64_planes(at, st));
+    } else {
+      a.out = w.qkv; a.ldo = 1536;
+      JV_TRY(rowgemm(a, RG_PLAIN, st));
+      at.ld = 1536; at.k_off = 512; at.v_off = 1024;
+      JV_TRY(attention64(at, st));
+    }
     a = rg_args(w.att, 512, b.out);      // h += to_out(att); ln = LayerNorm3(h)
     a.out = h; a.ldo = 256; a.res = h; a.ldr = 256;
     a.out2 = reinterpret_cast<unsigned short*>(w.ln); a.out2_plane = R * 256; a.ldo2 = 256; a.out2_scale = b.ff1.a_scale;

@@ -53,33 +53,50 @@ int f0_head(const float* h, const float* w, const float* bias, float* f0, int B,
 
 // ---- sine generator phase: frac[b,h,n] = (cumsum_n f0[b, n/480]*(h+1)/24000) mod 1 --------------------------
 // The reference's torch.cumsum (CPU) accumulates sequentially in fp64 and rounds every prefix to fp32; the running sum
-// reaches ~1e4 where one fp32 ulp is ~1e-3 cycles, so that rounding *is* part of the signal.  Each (utterance, harmonic)
-// is therefore accumulated by one lane in the same order and precision; 9*B lanes x 480*T dependent fp64 adds is well
-// under a millisecond at 6 s of audio.
-__global__ void sine_phase_kernel(const float* __restrict__ f0, float* __restrict__ frac, int B, int T) {
+// reaches ~1e4 where one fp32 ulp is ~1e-3 cycles, so that rounding *is* part of the signal and the sequential order has
+// to be reproduced, not approximated.  What makes that parallel: inside a mel frame the increment F is one fp32 value,
+// and as long as the fp64 sum's ulp is no coarser than F's last fp32 bit, every one of the 480 additions is EXACT -- the
+// prefix after k additions is start + k F with no rounding at all, whatever the order.  (F's last bit is 2^(e-23) for
+// F in [2^e, 2^(e+1)); the sum's ulp is 2^(E-52): exact iff E - 52 <= e - 23, i.e. for every voiced frame of speech --
+// f0 (h+1) > ~0.1 Hz after a minute of audio.)  So:
+// (and the frame's start value must itself be a multiple of the end value's ulp).
+//   1. frame_scan: one lane per (utterance, harmonic) walks the T frames (not the 480 T samples), adding 480 F in one exact
+//      step, and falls back to the 480 sequential additions for a frame that fails the test (f0 ~ 0: rare);
+//   2. source_mix evaluates frac = start + (k + 1) F per sample directly (exact frames), or re-runs the frame's sequential
+//      additions up to its sample (inexact frames) -- the 9 x 480 T phase tensor is never written or read.
+// Round 1 ran the 480 T dependent additions in one lane per (utterance, harmonic): 1.6 ms per pass.
+__device__ __forceinline__ bool frame_adds_exact(const double start, const float F) {
+  // exponent fields: start + 480 F stays below 2^(E+1) with E taken from the frame's end value
+  const double end = start + 480.0 * (double)F;
+  const int E = (int)((__double_as_longlong(end) >> 52) & 0x7ff) - 1023;
+  const int e = (int)((__float_as_uint(F) >> 23) & 0xff) - 127;
+  if (F == 0.f) return true;
+  if (((__float_as_uint(F) >> 23) & 0xff) == 0 || E - 52 > e - 23) return false;      // (subnormal F: take the sequential path)
+  // start itself must sit on the end value's grid too (it does unless the frame crosses into a higher binade with start's
+  // last bits set: the sequential additions would round there)
+  const double q = scalbn(start, 52 - E);
+  return q == trunc(q);
+}
+
+__global__ void sine_frame_scan_kernel(const float* __restrict__ f0, double* __restrict__ start, int B, int T) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * 9) return;
   const int b = idx / 9, h = idx - b * 9;
   const float mult = (float)(h + 1);
   double cum = 0.0;
-  float* dst = frac + (long)idx * T * 480;
   for (int t = 0; t < T; ++t) {
+    start[(long)idx * T + t] = cum;
     const float F = f0[b * T + t] * mult / 24000.0f;
-    for (int k = 0; k < 480; k += 4) {
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        cum = cum + (double)F;
-        const float c32 = (float)cum;
-        o[e] = c32 - floorf(c32);
-      }
-      *reinterpret_cast<f32x4*>(dst + (long)t * 480 + k) = o;
+    if (frame_adds_exact(cum, F)) {
+      cum = cum + 480.0 * (double)F;      // exact product (24 x 9 bits), exact sum
+    } else {
+      for (int k = 0; k < 480; ++k) cum = cum + (double)F;
     }
   }
 }
 
 // s[b,n] = tanh( lin_b + sum_h lin_w[h] * ( 0.1 sin(2 pi frac + phi_h) * uv + namp * noise ) )
-__global__ __launch_bounds__(256) void source_mix_kernel(const float* __restrict__ f0, const float* __restrict__ frac,
+__global__ __launch_bounds__(256) void source_mix_kernel(const float* __restrict__ f0, const double* __restrict__ start,
                                                          const float* __restrict__ phase, const float* __restrict__ noise,
                                                          const float* __restrict__ lin_w, const float* __restrict__ lin_b,
                                                          float* __restrict__ s, int B, int T) {
@@ -88,25 +105,38 @@ __global__ __launch_bounds__(256) void source_mix_kernel(const float* __restrict
   if (idx >= n_per * B) return;
   const int b = (int)(idx / n_per);
   const long n = idx - (long)b * n_per;
-  const float f = f0[b * T + (int)(n / 480)];
+  const int t = (int)(n / 480), k = (int)(n - (long)t * 480);
+  const float f = f0[b * T + t];
   const float uv = f > 10.0f ? 1.f : 0.f;
   const float namp = uv * 0.003f + (1.f - uv) * 0.1f / 3.f;
   float acc = 0.f;
 #pragma unroll
   for (int h = 0; h < 9; ++h) {
-    const long o = ((long)b * 9 + h) * n_per + n;
-    const float theta = 2.0f * 3.14159265358979323846f * frac[o];
+    const float F = f * (float)(h + 1) / 24000.0f;
+    const double st = start[((long)b * 9 + h) * T + t];
+    double cum;
+    if (frame_adds_exact(st, F)) {
+      cum = st + (double)(k + 1) * (double)F;
+    } else {
+      cum = st;
+      for (int j = 0; j <= k; ++j) cum = cum + (double)F;
+    }
+    const float c32 = (float)cum;
+    const float frac = c32 - floorf(c32);
+    const float theta = 2.0f * 3.14159265358979323846f * frac;
     const float ph = h == 0 ? 0.f : phase[b * 9 + h];
     const float sine = 0.1f * sinf(theta + ph);
-    acc += (sine * uv + namp * noise[o]) * lin_w[h];
+    acc += (sine * uv + namp * noise[((long)b * 9 + h) * n_per + n]) * lin_w[h];
   }
   s[idx] = tanhf(acc + lin_b[0]);
 }
 
 int sine_source(const float* f0, const float* phase, const float* noise, const float* lin_w, const float* lin_b, float* frac,
                 float* s, int B, int T, hipStream_t st) {
-  hipLaunchKernelGGL(sine_phase_kernel, dim3(cdiv(B * 9, 64)), dim3(64), 0, st, f0, frac, B, T);
-  hipLaunchKernelGGL(source_mix_kernel, dim3((unsigned)cdivl((long)B * T * 480, 256)), dim3(256), 0, st, f0, frac, phase, noise,
+  // `frac` (sized [B, 9, 480 T] floats by hift_ws_create) now only holds the [B, 9, T] frame-start sums, as doubles
+  double* start = reinterpret_cast<double*>(frac);
+  hipLaunchKernelGGL(sine_frame_scan_kernel, dim3(cdiv(B * 9, 64)), dim3(64), 0, st, f0, start, B, T);
+  hipLaunchKernelGGL(source_mix_kernel, dim3((unsigned)cdivl((long)B * T * 480, 256)), dim3(256), 0, st, f0, start, phase, noise,
                      lin_w, lin_b, s, B, T);
   JV_HIP(hipGetLastError());
   return JV_OK;

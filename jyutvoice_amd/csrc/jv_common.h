@@ -182,10 +182,16 @@ struct AttnArgs {
   unsigned short* out2;
   long out2_plane;
   float out2_scale;
+  // attention64_planes (attention_pl.hip): K and V pre-split by the qkv GEMM's epilogue -- fp16 planes [2][rows][kv_ld] of
+  // k * k_scale (columns 0..511) and v * v_scale (columns 512..1023); q stays fp32 in qkv (row stride ld)
+  const unsigned short* kv2;
+  long kv2_plane;
+  int kv_ld;
   int chunk;          // > 0: chunk-causal (streaming) mask -- query i sees keys j < (i / chunk + 1) * chunk; 0: all keys
   int ablate;         // tuning aid (JV_ABLATE): 1 no K/V loads, 2 no split + LDS stores, 4 no barriers, 8 no PV, 16 no QK^T, 32 no softmax
 };
 int attention64(const AttnArgs& a, hipStream_t st);
+int attention64_planes(const AttnArgs& a, hipStream_t st);
 
 // ---- row-wise / elementwise kernels (rowops.hip) -------------------------------------------------
 // out = LayerNorm_C(x (+ add)) * g + b, optional ReLU, rows with rowmask_out == 0 written as zero

@@ -20,7 +20,7 @@ int rg_launch2(const RowGemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((rowgemm_kernel<RT, EPI>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rg_lds_bytes<RT>(), st, a);
   if (prof) {
     static const std::string name = std::string("rowgemm_h3<") + std::to_string(16 * RT) + "x256" +
-                                    (EPI == RG_GELU_PL ? ",gelu" : EPI == RG_RES ? ",res" : EPI == RG_RES_LN ? ",res,ln" : "") + ">";
+                                    (EPI == RG_GELU_PL ? ",gelu" : EPI == RG_RES ? ",res" : EPI == RG_RES_LN ? ",res,ln" : EPI == RG_QKV ? ",qkv" : "") + ">";
     const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M);
     const double bytes = 4.0 * (rows * a.K + (double)a.N * a.K + rows * a.N * ((EPI == RG_RES || EPI == RG_RES_LN) ? 2 : 1) +
                                 (EPI == RG_RES_LN ? rows * 256 : 0));
@@ -37,6 +37,7 @@ int rg_launch1(const RowGemmArgs& a, int epi, hipStream_t st) {
     case RG_GELU_PL: return rg_launch2<RT, RG_GELU_PL>(a, st);
     case RG_RES: return rg_launch2<RT, RG_RES>(a, st);
     case RG_RES_LN: return rg_launch2<RT, RG_RES_LN>(a, st);
+    case RG_QKV: return rg_launch2<RT, RG_QKV>(a, st);
     default: return fail(JV_ERR_ARG, "rowgemm: unknown epilogue");
   }
 }
@@ -68,6 +69,8 @@ int rowgemm(const RowGemmArgs& a, int epi, hipStream_t st) {
   if ((epi == RG_RES || epi == RG_RES_LN) && (a.N != 256 || !a.res || !a.out || (a.ldo & 3) || (a.ldr & 3)))
     return fail(JV_ERR_ARG, "rowgemm: the residual epilogues own whole 256-wide rows");
   if (epi == RG_PLAIN && (!a.out || (a.ldo & 3))) return fail(JV_ERR_ARG, "rowgemm: bad output");
+  if (epi == RG_QKV && (a.N != 1536 || !a.out || !a.out2 || (a.ldo & 3) || (a.ldo2 & 3)))
+    return fail(JV_ERR_ARG, "rowgemm: the qkv epilogue wants N = 1536, a q buffer and a K/V plane buffer");
   if ((epi == RG_GELU_PL || epi == RG_RES_LN) && (!a.out2 || (a.ldo2 & 3))) return fail(JV_ERR_ARG, "rowgemm: bad plane output");
   if (epi == RG_RES_LN && (!a.ln_g || !a.ln_b)) return fail(JV_ERR_ARG, "rowgemm: LayerNorm epilogue needs gain and offset");
   int rt = rowgemm_tile(a.M);

@@ -39,6 +39,8 @@ enum RowGemmEpi : int {
   RG_GELU_PL = 1,    // gelu(...) written as fp16 planes of value * out2_scale (ff.net.0 -> ff.net.2's operand)
   RG_RES = 2,        // ... + res -> fp32 rows (+ amax tracking)
   RG_RES_LN = 3,     // ... + res -> fp32 rows, then LayerNorm_256 of the row -> fp16 planes * ln_scale (the next GEMM's operand)
+  RG_QKV = 4,        // N = 1536 = q | k | v: q -> fp32 rows [.,512] (out), k and v -> fp16 planes [2][rows][1024] (out2) of
+                     // k * out2_scale, v * out2_scale2: the operands attention64_planes takes without splitting anything
 };
 
 struct RowGemmArgs {
@@ -61,7 +63,7 @@ struct RowGemmArgs {
   unsigned short* out2;      // RG_GELU_PL: [2][rows][ldo2];  RG_RES_LN: the LayerNorm planes [2][rows][256]
   long out2_plane;
   int ldo2;
-  float out2_scale;
+  float out2_scale, out2_scale2;
   const float *ln_g, *ln_b;
   float ln_eps;
   // measured-bound tracking of what RG_RES / RG_RES_LN store (ConvGemmArgs::amax_out): slot = row_slot[m], rows with
@@ -293,6 +295,23 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const RowGemmArgs p) {
 #pragma unroll
         for (int j = 0; j < RPW; ++j)
           if (ok[j]) *reinterpret_cast<rg_f32x4*>(p.out + mrow[j] * p.ldo + n0) = v[j];
+      } else if constexpr (EPI == RG_QKV) {
+        if (c < 2) {      // q (chunk-uniform branch)
+#pragma unroll
+          for (int j = 0; j < RPW; ++j)
+            if (ok[j]) *reinterpret_cast<rg_f32x4*>(p.out + mrow[j] * p.ldo + n0) = v[j];
+        } else {
+          const float sc = c < 4 ? p.out2_scale : p.out2_scale2;
+#pragma unroll
+          for (int j = 0; j < RPW; ++j) {
+            if (!ok[j]) continue;
+            const Split2 s0 = split2h_pair(v[j][0] * sc, v[j][1] * sc);
+            const Split2 s1 = split2h_pair(v[j][2] * sc, v[j][3] * sc);
+            unsigned short* o2 = p.out2 + mrow[j] * p.ldo2 + (n0 - 512);
+            *reinterpret_cast<rg_u32x2*>(o2) = rg_u32x2{s0.h, s1.h};
+            *reinterpret_cast<rg_u32x2*>(o2 + p.out2_plane) = rg_u32x2{s0.l, s1.l};
+          }
+        }
       } else if constexpr (EPI == RG_GELU_PL) {
 #pragma unroll
         for (int j = 0; j < RPW; ++j) {

@@ -468,7 +468,7 @@ int layernorm256_planes(const float* x, unsigned short* out2, long plane, float 
 
 // fp32 rows [rows][C] (row stride ld) -> two fp16 planes [2][rows][C] of x * scale (the A operand of the fp16x3 GEMM)
 __global__ __launch_bounds__(256) void split2h_rows_kernel(const float* __restrict__ x, long ld, unsigned short* __restrict__ dst,
-                                                           long plane, long rows, int C, float scale) {
+                                                           long plane, long rows, int C, float scale, long ldd) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;      // pair index
   const int c2 = C >> 1;
   if (i >= rows * c2) return;
@@ -476,13 +476,13 @@ __global__ __launch_bounds__(256) void split2h_rows_kernel(const float* __restri
   const int c = (int)(i - r * c2) * 2;
   const float* s = x + r * ld + c;
   const Split2 t = split2h_pair(s[0] * scale, s[1] * scale);
-  *reinterpret_cast<unsigned*>(dst + r * C + c) = t.h;
-  *reinterpret_cast<unsigned*>(dst + plane + r * C + c) = t.l;
+  *reinterpret_cast<unsigned*>(dst + r * ldd + c) = t.h;
+  *reinterpret_cast<unsigned*>(dst + plane + r * ldd + c) = t.l;
 }
 
-int split2h_rows(const float* x, long ld, unsigned short* dst, long plane, long rows, int C, float scale, hipStream_t st) {
+int split2h_rows(const float* x, long ld, unsigned short* dst, long plane, long rows, int C, float scale, hipStream_t st, long ldd) {
   hipLaunchKernelGGL(split2h_rows_kernel, dim3((unsigned)cdivl(rows * (C >> 1), 256)), dim3(256), 0, st, x, ld, dst, plane, rows,
-                     C, scale);
+                     C, scale, ldd > 0 ? ldd : (long)C);
   JV_HIP(hipGetLastError());
   return JV_OK;
 }

@@ -303,6 +303,22 @@ def op_rowgemm(A, W, bias=None, epi="plain", res=None, ln=None, a_bound=None, ou
     return (out, planes) if code == 3 else out
 
 
+def op_attention_planes(qkv, lens, B, G, S, L, bounds=None, chunk=0, planes_out=False, out2_scale=256.0):
+    """attention_pl.hip (K / V as fp16 planes by LDS-DMA); planes_out: the result through the fp16-plane output path, returned
+    un-scaled as fp64"""
+    lib = _lib.load()
+    rows = qkv.shape[0]
+    if bounds is None:
+        bounds = tuple(float(qkv[:, o:o + 512].abs().max()) for o in (0, 512, 1024))
+    out = torch.zeros(rows, 512, device=qkv.device)
+    out2 = torch.zeros(2, rows, 512, dtype=torch.float16, device=qkv.device) if planes_out else None
+    check(lib.jv_op_attention_planes(_ptr(qkv), rows, _ptr(lens), B, G, S, L, float(bounds[0]), float(bounds[1]), float(bounds[2]),
+                                     int(chunk), float(out2_scale), _ptr(out), _ptr(out2), _stream(qkv.device)))
+    if planes_out:
+        return (out2[0].double() + out2[1].double()) / out2_scale
+    return out
+
+
 def op_layernorm(x, g, b, eps=1e-5):
     lib = _lib.load()
     out = torch.empty_like(x)

@@ -80,6 +80,27 @@ def test_hift_source(eng, hift_sd):
     assert md(s, g["s"]) <= 2e-4               # fixture keeps the noise draw in fp16
 
 
+def test_hift_source_long_and_unvoiced(eng, hift_sd):
+    """the phase of the sine generator is torch.cumsum's sequential fp64 sum rounded to fp32 per sample; the kernel gets it in
+    parallel from per-frame start values (hiftops.hip: exact whenever the sum's ulp is no coarser than the increment's last
+    bit) and re-runs the sequential additions where that fails -- frames with f0 ~ 0 after seconds of audio.  Both paths,
+    4 s of audio, against the oracle sample for sample"""
+    from oracle import hift as ohift
+    g = torch.Generator().manual_seed(91)
+    B, T = 2, 200
+    f0 = 60.0 + 300.0 * torch.rand(B, T, generator=g)
+    f0[0, 40:60] = 0.0                     # unvoiced stretch
+    f0[0, 100:110] = 3.0e-5                # increments far below the running sum's ulp: the sequential fallback
+    f0[1, 150:170] = 1.0e-3
+    f0[1, 5] = 1.0e-7
+    phase = (torch.rand(B, 9, 1, generator=g) * 2 - 1) * 3.14159
+    phase[:, 0] = 0
+    noise = torch.randn(B, 9, 480 * T, generator=g)
+    s = eng.hift_source(f0, phase.squeeze(-1), noise)
+    want = ohift.source(ohift.fold_weight_norm(hift_sd), f0, phase, noise)
+    assert md(s, want) <= 2e-5
+
+
 def test_hift_decode_golden(eng):
     g = load_golden("G5_hift")
     wav = eng.hift_decode(g["mel"], g["s"])

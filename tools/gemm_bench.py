@@ -15,7 +15,7 @@ os.environ.setdefault("JV_DYNAMIC_ENV", "1")
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from jyutvoice_amd.engine import op_attention, op_attention_h3, op_conv_gemm, op_linear_h3, op_rowgemm  # noqa: E402
+from jyutvoice_amd.engine import op_attention_planes, op_attention, op_attention_h3, op_conv_gemm, op_linear_h3, op_rowgemm  # noqa: E402
 
 dev = torch.device("cuda:0")
 M = int(os.environ.get("JV_M", 4 + 64 * 304))
@@ -78,7 +78,10 @@ for L in ((int(os.environ["JV_ATTN_L"]),) if os.environ.get("JV_ATTN_L") else (3
     S = L + 4
     qkv = torch.randn(4 + B * S + 8, 1536, generator=g).to(dev)
     lens = torch.full((B,), L, dtype=torch.int32, device=dev)
-    if os.environ.get("JV_OP_H3"):      # fp16x3 attention with bounds as a load-time L1-norm bound would give them
+    if os.environ.get("JV_OP_ATTN_PL"):      # K / V as planes by LDS-DMA (attention_pl.hip)
+        bounds = tuple(8.0 * float(qkv[:, o:o + 512].abs().max()) for o in (0, 512, 1024))
+        t = timeit(lambda: op_attention_planes(qkv, lens, B, 4, S, L, bounds))
+    elif os.environ.get("JV_OP_H3"):      # fp16x3 attention with bounds as a load-time L1-norm bound would give them
         bounds = tuple(8.0 * float(qkv[:, o:o + 512].abs().max()) for o in (0, 512, 1024))
         t = timeit(lambda: op_attention_h3(qkv, lens, B, 4, S, L, bounds))
     else:
