@@ -39,7 +39,7 @@ def pmc_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from the committed PMC passes (tools/profile.sh: rocprofv3 --pmc FETCH_SIZE, doubled
     as MI355X_MICROARCH.md prescribes for gfx950, and --pmc WRITE_SIZE; counters cannot be read from inside this process).
     Only quoted for the workload those passes ran (the default C3 shape); null otherwise."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
     if (args.batch, args.tokens, args.timesteps) != (32, 150, 10) or not os.path.exists(path):
         return {}
     with open(path) as fh:
@@ -48,7 +48,7 @@ def pmc_traffic(kernel, args):
     if not k or "fetch_bytes" not in k or "write_bytes" not in k:
         return {}
     return {"traffic": k["fetch_bytes"] + k["write_bytes"], "traffic_fetch": k["fetch_bytes"], "traffic_write": k["write_bytes"],
-            "traffic_source": "profiles/r01_final_pmc_traffic.json <- " + d["source"]}
+            "traffic_source": "profiles/r02_pmc_traffic.json <- " + d["source"]}
 
 
 def kernel_peak(name: str):
@@ -58,7 +58,7 @@ def kernel_peak(name: str):
         # the dense bf16 MFMA peak / 6
         return BF16_MFMA_PEAK_TFLOPS / 6.0, ("fp32 operands split into 3 bf16 planes, 6 x v_mfma_f32_32x32x16_bf16 per product, "
                                              "fp32 accumulate; peak = dense bf16 MFMA (2500) / 6")
-    if name.startswith("conv_gemm_h3") or name.startswith("attn64_h3") or name.startswith("rowgemm_h3"):
+    if name.startswith(("conv_gemm_h3", "attn64_h3", "attn64_pl", "rowgemm_h3")):
         # fp16x3: three fp16 MFMA products per fp32-accurate multiply-add (fp16 and bf16 MFMA rates are equal)
         return BF16_MFMA_PEAK_TFLOPS / 3.0, ("fp32 operands scaled by an exact power of two and split into 2 fp16 planes (22 bits), "
                                              "3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; peak = dense fp16 MFMA (2500) / 3")

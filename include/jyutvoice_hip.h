@@ -198,6 +198,13 @@ int jv_op_rowgemm(const float* A, int64_t rows, int M, int K, const float* W, in
  * out2 != NULL: result as fp16 planes [2][rows][512] of value * out2_scale, else fp32 rows in out [rows,512]. */
 int jv_op_attention_planes(const float* qkv, int64_t rows, const int32_t* lens, int B, int G, int S, int L, float q_bound,
                            float k_bound, float v_bound, int chunk, float out2_scale, float* out, uint16_t* out2, void* stream);
+/* jv_op_rowconv: the estimator's causal k = 3 convolution to 256 channels at chip-filling batch sizes (rowconv_kernel.h):
+ * out[m] = tail(sum_j A[m - 2 + j] W_j + bias), tail = LayerNorm_256 (ln_g != NULL) -> act -> rows with rowmask == 0 := 0 ->
+ * + rowvec (one [256] vector here) -> + res; A's fp16x3 scale comes from *amax_in (>= max |A|), amax_out receives max |out|
+ * over the unmasked rows (decoder.py:110-115, 767-788). */
+int jv_op_rowconv(const float* A, int64_t rows, int M, int Cin, const float* W, const float* bias, const float* ln_g,
+                  const float* ln_b, int act, const uint8_t* rowmask, const float* rowvec, const float* res,
+                  const float* amax_in, float* amax_out, float* out, void* stream);
 int jv_op_layernorm(const float* x, const float* g, const float* b, float eps, int64_t rows, int C, float* out,
                     void* stream);
 

@@ -7,11 +7,12 @@
 #include "../../include/jyutvoice_hip.h"
 #include "jv_model.h"
 #include "jv_ops.h"
-#include "rowgemm_kernel.h"
+#include "rowconv_kernel.h"
 
 namespace jv {
 
 int rowgemm(const RowGemmArgs& a, int epi, hipStream_t st);   // rowgemm.hip
+int rowconv(const RowConvArgs& a, hipStream_t st);
 
 int split3_planes(const float* src, unsigned short* dst, long n, hipStream_t st);   // registry.hip
 int split2h_planes(const float* src, int rows, int ld, float* stats, unsigned short* dst, float* colscale, hipStream_t st);
@@ -440,6 +441,37 @@ int jv_op_rowgemm(const float* A, int64_t rows, int M, int K, const float* W, in
   a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
   a.amax_out = amax_out;
   return jv::rowgemm(a, epi, st);
+}
+
+// the row-owning causal k = 3 convolution (rowconv_kernel.h) with its fused row-wise tail (test / tuning hook): one
+// measured-bound slot (amax_in, a device float >= max |A|), W [256, 3 Cin] packed tap-major like jv_op_conv_gemm
+int jv_op_rowconv(const float* A, int64_t rows, int M, int Cin, const float* W, const float* bias, const float* ln_g,
+                  const float* ln_b, int act, const uint8_t* rowmask, const float* rowvec, const float* res,
+                  const float* amax_in, float* amax_out, float* out, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int N = 256, K = 3 * Cin;
+  static void* scratch = nullptr;
+  static size_t cap = 0;
+  const size_t n = (size_t)N * K;
+  const size_t need = n * 4 + (size_t)N * 12 + 256 + (size_t)rows * sizeof(int);
+  if (need > cap) {
+    if (scratch) (void)hipFree(scratch);
+    JV_HIP(hipMalloc(&scratch, need));
+    cap = need;
+  }
+  unsigned short* planes = static_cast<unsigned short*>(scratch);
+  float* cs = reinterpret_cast<float*>(static_cast<char*>(scratch) + ((n * 4 + 63) & ~(size_t)63));
+  int* slots = reinterpret_cast<int*>(cs + 3 * N + 16);
+  JV_TRY(jv::split2h_planes(W, N, K, cs + N, planes, cs, st));
+  JV_HIP(hipMemsetAsync(slots, 0, (size_t)rows * sizeof(int), st));
+  jv::RowConvArgs a{};
+  a.A = A; a.lda = Cin; a.a_rows = rows; a.M = M; a.Cin = Cin; a.rowmask_in = rowmask;
+  a.W2 = planes; a.w2_plane = (long)n; a.ldw = K; a.colscale = cs; a.amax_in = amax_in; a.row_slot = slots; a.bias = bias;
+  a.out = out; a.ldo = N;
+  if (ln_g) { a.ln = 1; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f; }
+  a.act = act; a.rowmask_out = rowmask; a.rowvec = rowvec; a.rowvec_ld = N; a.res = res; a.ldr = N;
+  a.amax_out = amax_out; a.row_mask = rowmask;
+  return jv::rowconv(a, st);
 }
 
 // attention64_planes (attention_pl.hip) on an fp32 qkv matrix: K and V are split into planes here the way the qkv GEMM's

@@ -134,7 +134,10 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
     for (int i = 0; i < NR; ++i) {
       const float* src = asrc[i] + c0 * astep[i];
 #pragma unroll
-      for (int v = 0; v < 2 * NG; ++v) pa[i][v] = *reinterpret_cast<const f32x4*>(src + 4 * v);
+      for (int v = 0; v < 2 * NG; ++v)      // explicitly GLOBAL: through a generic pointer (A or the zero page) these are flat_load,
+                                            // which counts on lgkmcnt too -- every wait for an LDS fragment then also waits for the
+                                            // prefetch of the next step's A rows
+        pa[i][v] = *(const __attribute__((address_space(1))) f32x4*)(src + 4 * v);
     }
   };
   auto store_A = [&](int c0) {

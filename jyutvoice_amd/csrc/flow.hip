@@ -12,11 +12,12 @@
 
 #include "jv_model.h"
 #include "jv_ops.h"
-#include "rowgemm_kernel.h"
+#include "rowconv_kernel.h"
 
 namespace jv {
 
 int rowgemm(const RowGemmArgs& a, int epi, hipStream_t st);   // rowgemm.hip
+int rowconv(const RowConvArgs& a, hipStream_t st);
 int rowgemm_tile(int M);
 
 constexpr int FLOW_G = 4;      // leading guard rows (>= causal left context 2)
@@ -193,6 +194,23 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.W2 = m.w2; a.w2_plane = (long)m.n_rows * m.ldw; a.colscale = m.colscale; a.amax_in = slots_of(a.A); a.a_extra = 0.f;
     amax_geo(a);
   };
+  // A causal k = 3 convolution of a trunk buffer: on the row-owning kernel (rowconv_kernel.h: LayerNorm / Mish / mask / time
+  // embedding / residual in its epilogue, no ln_epilogue_rows pass) when the batch fills the chip, else on the tile kernels
+  const bool use_rc = !c.exact_range && !c.no_rowgemm && rowgemm_tile((int)g.M) > 0;
+  auto conv3 = [&](ConvGemmArgs& a, const GemmW& m) -> int {
+    if (!use_rc || !a.amax_in || !m.w2 || a.ntaps != 3 || a.tap_row0 != -2 || a.N != 256 || a.ldo != 256 && a.ldo != 512)
+      return conv_gemm(a, 1, st);
+    RowConvArgs r{};
+    r.A = a.A; r.lda = a.lda; r.a_rows = a.a_rows; r.M = a.M; r.Cin = a.Cin; r.rowmask_in = a.rowmask_in;
+    r.W2 = m.w2; r.w2_plane = (long)m.n_rows * m.ldw; r.ldw = m.ldw; r.colscale = m.colscale;
+    r.amax_in = a.amax_in; r.row_slot = w.row_sample; r.bias = a.bias;
+    r.out = a.out; r.ldo = a.ldo;
+    r.ln = a.ln; r.ln_g = a.ln_g; r.ln_b = a.ln_b; r.ln_eps = a.ln_eps; r.act = a.act; r.rowmask_out = a.rowmask_out;
+    r.rowvec = a.rowvec; r.rowvec_ld = a.rowvec_ld; r.res = a.res1; r.ldr = a.ldr1;
+    r.amax_out = a.amax_out; r.row_mask = w.rowmask;
+    r.alg_rows = a.alg_rows;
+    return rowconv(r, st);
+  };
   // CausalResnetBlock1D (decoder.py:110-115, 784-795)
   auto resnet = [&](int i, const float* in, int ldin, float* out, int ldo) -> int {
     const ResnetW& r = e.res[i];
@@ -203,7 +221,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.rowvec = w.temb + i * 256; a.row_sample = w.row_sample; a.rowvec_ld = EST_NRES * 256;
     h3m(a, r.block1);
     track(a);      // -> h2
-    JV_TRY(conv_gemm(a, 1, st));
+    JV_TRY(conv3(a, r.block1));
     a = base_args(g, in, ldin, r.res, w.res, 256);
     a.rowmask_in = w.rowmask;
     h3m(a, r.res);
@@ -215,7 +233,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.res1 = w.res; a.ldr1 = 256;
     h3m(a, r.block2);
     track(a);      // -> h
-    return conv_gemm(a, 1, st);
+    return conv3(a, r.block2);
   };
   // BasicTransformerBlock (transformer.py:355-443): h -> h, last GEMM may retarget its output
   // the four linears of a block run fp16x3 when registry.hip proved their input range (GemmW::a_scale)
@@ -365,7 +383,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     causal3(a);
     h3m(a, e.down_conv);
     track(a);
-    JV_TRY(conv_gemm(a, 1, st));
+    JV_TRY(conv3(a, e.down_conv));
   }
   // mid x12; the last block writes straight into columns [0,256) of the concat buffer
   for (int i = 1; i <= EST_NMID; ++i) {
@@ -380,14 +398,14 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     causal3(a);
     h3m(a, e.up_conv);
     track(a);
-    JV_TRY(conv_gemm(a, 1, st));
+    JV_TRY(conv3(a, e.up_conv));
     a = base_args(g, w.h2, 256, e.final_conv, w.h, 256);
     causal3(a);
     a.ln = 1; a.ln_g = e.final_ln.g; a.ln_b = e.final_ln.b; a.ln_eps = 1e-5f; a.act = ACT_MISH;
     a.rowmask_out = w.rowmask;
     h3m(a, e.final_conv);
     track(a);
-    JV_TRY(conv_gemm(a, 1, st));
+    JV_TRY(conv3(a, e.final_conv));
     a = base_args(g, w.h, 256, e.final_proj, w.d, 80);
     a.rowmask_in = w.rowmask;
     a.rowmask_out = w.rowmask;

@@ -70,6 +70,15 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
+// Mish with the raw v_exp_f32 and v_rcp_f32 (each ~1 ulp) instead of expf and an IEEE division: the same x n / (n + 2)
+// form as act_apply, ~9 instructions instead of ~25.  For epilogues that run on the few waves of a row-owning workgroup,
+// where nothing hides VALU latency (rowconv_kernel.h); relative error vs fp64 <= 5e-7, the same order as act_apply's 3.6e-7.
+__device__ __forceinline__ float mish_fast(const float v) {
+  const float e = __builtin_amdgcn_exp2f(fminf(v, 20.f) * 1.44269504088896340736f);
+  const float n = e * (e + 2.f);
+  return v > 20.f ? v : v * (n * __builtin_amdgcn_rcpf(n + 2.f));
+}
+
 // sin^2(a) for the Snake activation x + sin^2(alpha x) / alpha (jyutvoice/hifigan/generator.py Snake).  sinf() costs ~130
 // VALU instructions per value on gfx950 (its Payne-Hanek path is compiled in line), which made the Snake-prologue
 // convolutions VALU-bound.  Here: a = k pi + r with a two-constant Cody-Waite reduction (exact products through fma; the

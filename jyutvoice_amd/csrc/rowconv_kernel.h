@@ -1,0 +1,340 @@
+// Row-owning fp16x3 causal convolution (k = 3, 256 output channels) for the estimator's trunk: the two CausalBlock1D
+// convolutions of every CausalResnetBlock1D and the down / up / final causal convolutions (jyutvoice/flow/decoder.py:110-115,
+// 767-788, 976-1012), with what follows each of them row-wise in its epilogue: LayerNorm over the 256 channels -> Mish ->
+// mask -> + time embedding -> + residual (the former ln_epilogue_rows pass), and the measured-bound tracking.
+//
+// Same skeleton as rowgemm_kernel.h (one 8-wave workgroup per CU owns 16 RT whole rows x all 256 columns; weights by LDS-DMA
+// into a 3-stage ring with counted waits and one barrier per step; v_mfma_f32_16x16x32_f16), with two differences:
+//   * a step is (32-channel chunk c, tap j): the weight tile of a step is W[:, j Cin + 32 c .. + 32]; the A operand of the
+//     three taps of a chunk is ONE window of 16 RT + 2 rows, staged once per chunk and read at row offsets 0, 1, 2 (the
+//     slot key of rowgemm_kernel.h is conflict-free at every row offset);
+//   * A is the residual stream itself -- fp32 rows whose bound is MEASURED, per utterance (ConvGemmArgs::amax_in) -- so it is
+//     split here: 16 RT + 2 rows x 32 channels per chunk over 512 threads is two float4 per thread, against a 64x64 tile
+//     kernel that split the same window once per column tile (4x) -- the vector work per MFMA drops 4x, the barriers 3x.
+#pragma once
+#include "rowgemm_kernel.h"
+
+namespace jv {
+
+struct RowConvArgs {
+  const float* A;      // fp32 row buffer; output row m reads rows m - 2, m - 1, m (rows outside [0, a_rows) or masked: zero)
+  long lda, a_rows;
+  int M, Cin;          // Cin % 32 == 0
+  const unsigned char* rowmask_in;
+  const unsigned short* W2;      // fp16 planes [2][256][ldw] of W[n][j Cin + ci] * 2^e_n, colscale[n] = 2^-e_n
+  long w2_plane;
+  int ldw;
+  const float* colscale;
+  const float* amax_in;          // per-utterance bound of A (slot = row_slot[row])
+  const int* row_slot;
+  const float* bias;
+  float* out;
+  long ldo;
+  int ln;                        // LayerNorm over the 256 columns, then act, in the epilogue
+  const float *ln_g, *ln_b;
+  float ln_eps;
+  int act;
+  const unsigned char* rowmask_out;      // 0 -> value := 0 (before the additions below)
+  const float* rowvec;                   // + rowvec[row_slot[m] * rowvec_ld + n]
+  int rowvec_ld;
+  const float* res;                      // + res[m * ldr + n]
+  long ldr;
+  float* amax_out;                       // tracking of what is stored (rows with row_mask == 0 excluded)
+  const unsigned char* row_mask;
+  long alg_rows;
+  int ablate;      // tuning aid (JV_RG_ABLATE, tuning builds): 1 no weight DMA in the loop, 2 no LDS reads + MFMAs, 4 no waits / barriers,
+                   // 8 no A staging in the loop, 16 no epilogue
+};
+
+__device__ __attribute__((aligned(64))) const float rc_zero_page[16] = {};
+
+template <int RT> constexpr int rc_a_plane() { return (16 * RT + 16) * 64; }
+template <int RT> constexpr int rc_lds_bytes() { return 3 * 32768 + 2 * 2 * rc_a_plane<RT>() + 16 * RT * 8; }
+static_assert(16 * 5 * RG_SLD * 4 <= 3 * 32768, "the epilogue slab of the tallest tile fits the weight ring");
+
+template <int RT>
+__global__ __launch_bounds__(512, 2) void rowconv_kernel(const RowConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rc_lds[];
+  constexpr int R = 16 * RT, WR = R + 2;
+  constexpr int WSTAGE = 32768, W_PLANE = 256 * 64;
+  constexpr int A_PLANE = rc_a_plane<RT>(), A_BUF = 2 * A_PLANE, A_OFF = 3 * WSTAGE;
+  constexpr int NI = (WR * 8 + 511) / 512;      // float4 per thread per chunk (window rows x 8 float4)
+  constexpr int PPW = 4;                        // weight pieces per wave and step: 2 planes x 16 groups / 8 waves
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * R;
+  const int NCH = p.Cin >> 5;
+  const int total = 3 * NCH;
+
+  // warm this XCD's L2 with the weight planes (see rowgemm_kernel.h)
+  float warm = 0.f;
+  {
+    const long lpp = ((long)256 * p.ldw * 2) >> 7;
+    const int grp = blockIdx.x >> 3, ngrp = (gridDim.x + 7) >> 3;
+    const long per = (2 * lpp + ngrp - 1) / ngrp;
+    const long l = (long)grp * per + tid;
+    if (tid < per && l < 2 * lpp) {
+      const int pl = l >= lpp;
+      warm = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.W2 + (long)pl * p.w2_plane) + ((l - pl * lpp) << 7));
+    }
+  }
+
+  // ---- weight pieces of this wave: piece pc = wave + 8 i -> plane pc >> 4, 16-column group pc & 15
+  const unsigned short* cur[PPW];
+  int dst[PPW];
+  {
+    const int prow = lane >> 2, pslot = (lane & 3) ^ rg_key(prow);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave + 8 * i, pl = pc >> 4, g = pc & 15;
+      cur[i] = p.W2 + (long)pl * p.w2_plane + (long)(g * 16 + prow) * p.ldw + 8 * pslot;
+      dst[i] = pl * W_PLANE + g * 1024;
+    }
+  }
+  int ij = 0;      // tap of the next step to issue
+  auto issue_piece = [&](auto itag, int stage) {
+    constexpr int i = decltype(itag)::value;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)cur[i],
+                                     (__attribute__((address_space(3))) void*)(rc_lds + stage * WSTAGE + dst[i]), 16, 0, 0);
+  };
+  auto advance = [&]() {      // k offset of step (c, j) is j Cin + 32 c
+    const bool wrap = ++ij == 3;
+    if (wrap) ij = 0;
+    const int d = wrap ? 32 - 2 * p.Cin : p.Cin;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) cur[i] += d;
+  };
+  auto issue_all = [&](int stage) {
+    issue_piece(std::integral_constant<int, 0>{}, stage);
+    issue_piece(std::integral_constant<int, 1>{}, stage);
+    issue_piece(std::integral_constant<int, 2>{}, stage);
+    issue_piece(std::integral_constant<int, 3>{}, stage);
+    advance();
+  };
+
+  // The weight ring starts first: everything below (row slots -> measured bounds -> first A window) is a chain of dependent
+  // global loads, several microseconds that the first two weight tiles spend in flight
+  issue_all(0);
+  issue_all(1);      // total >= 3
+
+  // ---- per-row facts of this tile, read once here (two dependent loads per row) and kept in LDS for the epilogue:
+  // x = bits of 1 / a_scale of the row's utterance, y = its slot | flags
+  int2* const rowinfo = reinterpret_cast<int2*>(rc_lds + A_OFF + 2 * A_BUF);
+  constexpr int RI_KEEP = 1 << 29, RI_TRACK = 1 << 30;
+  if (tid < R) {
+    const long m = (long)m0 + tid;
+    int y = 0;
+    float inv = 0.f;
+    if (m < p.M) {
+      const int sl = p.row_slot[m];
+      inv = 1.0f / h3_scale_dev(p.amax_in[sl]);
+      y = sl;
+      if (!p.rowmask_out || p.rowmask_out[m] != 0) y |= RI_KEEP;
+      if (p.amax_out && (!p.row_mask || p.row_mask[m] != 0)) y |= RI_TRACK;
+    }
+    rowinfo[tid] = int2{(int)__float_as_uint(inv), y};
+  }
+
+  // ---- A window staging: thread -> (window row, float4) pairs, fixed over the chunks
+  const float* asrc[NI];
+  int astep[NI], adst[NI];
+  float ascale[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int idx = tid + 512 * i;
+    const int r = idx >> 3, c4 = idx & 7;
+    const long ar = (long)m0 - 2 + r;
+    bool ok = r < WR && ar >= 0 && ar < p.a_rows;
+    if (ok && p.rowmask_in) ok = p.rowmask_in[ar] != 0;
+    asrc[i] = ok ? p.A + ar * p.lda + 4 * c4 : rc_zero_page;
+    astep[i] = ok ? 1 : 0;
+    ascale[i] = ok ? h3_scale_dev(p.amax_in[p.row_slot[ar]]) : 0.f;
+    adst[i] = r < WR ? r * 64 + ((((c4 >> 1) ^ rg_key(r)) << 4) | ((c4 & 1) << 3)) : -1;
+  }
+  rg_f32x4 pa[NI];
+  auto load_A = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)      // explicitly GLOBAL loads: a generic pointer (A or the zero page) would make them flat_load, which
+                                      // counts on lgkmcnt as well and returns out of order -- no counted wait is valid beside it
+      pa[i] = *(const __attribute__((address_space(1))) rg_f32x4*)(asrc[i] + c * 32 * astep[i]);
+  };
+  auto store_A = [&](int buf) {
+    unsigned char* const base = rc_lds + A_OFF + buf * A_BUF;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (adst[i] >= 0) {
+        const Split2 s0 = split2h_pair(pa[i][0] * ascale[i], pa[i][1] * ascale[i]);
+        const Split2 s1 = split2h_pair(pa[i][2] * ascale[i], pa[i][3] * ascale[i]);
+        *reinterpret_cast<rg_u32x2*>(base + adst[i]) = rg_u32x2{s0.h, s1.h};
+        *reinterpret_cast<rg_u32x2*>(base + A_PLANE + adst[i]) = rg_u32x2{s0.l, s1.l};
+      }
+    }
+  };
+
+  const int w_off = (wave * 32 + r16) * 64 + ((kq ^ rg_key(r16)) << 4);      // + pl * W_PLANE + nt * 1024
+
+  rg_f32x4 acc[RT][2];
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // the epilogue's per-column constants, fetched here so that their latency is not paid behind the main loop
+  const rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.colscale + 4 * lane);
+  rg_f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) b4 = *reinterpret_cast<const rg_f32x4*>(p.bias + 4 * lane);
+  rg_f32x4 gg = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
+  if (p.ln) {
+    gg = *reinterpret_cast<const rg_f32x4*>(p.ln_g + 4 * lane);
+    bb = *reinterpret_cast<const rg_f32x4*>(p.ln_b + 4 * lane);
+  }
+  load_A(0);
+  store_A(0);
+  if (NCH > 1) load_A(1);
+  // vector-memory queue of this wave from here on, oldest first: W(0) W(1) (both waited for with A(0)) [A loads of chunk 1]
+  int s = 0;
+  for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j, ++s) {
+      // W(s) has landed once at most the operations issued after it are outstanding: W(s + 1), and the A loads of chunk
+      // c + 2 when they were issued behind W(s + 1) or W(s + 2) (the end of step (c, 0))
+      if (!JV_ABLATE(p, 4)) {
+        if (s + 1 >= total) rg_wait_vmcnt<0>();
+        else if (j != 0 && c + 2 < NCH && !JV_ABLATE(p, 8)) rg_wait_vmcnt<PPW + NI>();
+        else rg_wait_vmcnt<PPW>();
+        rg_lds_barrier();      // (+ this wave's A-plane stores of the previous chunk step are complete)
+      }
+      const bool more = s + 2 < total && !JV_ABLATE(p, 1);
+      const int nstage = (s + 2) % 3;
+      if (j == 0 && c + 1 < NCH && !JV_ABLATE(p, 8)) store_A((c + 1) & 1);      // its registers were loaded a chunk ago; buffer last read in chunk c - 1
+      if (JV_ABLATE(p, 2)) {
+        if (more) issue_all(nstage);
+        if (j == 0 && c + 2 < NCH && !JV_ABLATE(p, 8)) load_A(c + 2);
+        continue;
+      }
+      const unsigned char* const sw = rc_lds + (s % 3) * WSTAGE;
+      const unsigned char* const sa = rc_lds + A_OFF + (c & 1) * A_BUF;
+      rg_u32x4 b[2][2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) b[nt][pl] = *reinterpret_cast<const rg_u32x4*>(sw + w_off + pl * W_PLANE + nt * 1024);
+      auto group = [&](auto mtag) {
+        constexpr int mt = decltype(mtag)::value;
+        const int row = mt * 16 + r16 + j;
+        const int a_off = row * 64 + ((kq ^ rg_key(row)) << 4);
+        rg_u32x4 a[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) a[pl] = *reinterpret_cast<const rg_u32x4*>(sa + pl * A_PLANE + a_off);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          rg_f32x4 t = acc[mt][nt];
+          auto mm = [&](const rg_u32x4& x, const rg_u32x4& y) {
+            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rg_f16x8, x), __builtin_bit_cast(rg_f16x8, y), t, 0, 0, 0);
+          };
+          mm(a[1], b[nt][0]);
+          mm(a[0], b[nt][1]);
+          mm(a[0], b[nt][0]);
+          acc[mt][nt] = t;
+        }
+        if (more) {
+          if constexpr (mt < PPW) issue_piece(std::integral_constant<int, (mt < PPW ? mt : 0)>{}, nstage);
+          if constexpr (mt == RT - 1 && RT < PPW) {      // fewer groups than pieces: the rest behind the last group
+            if constexpr (RT <= 1) issue_piece(std::integral_constant<int, 1>{}, nstage);
+            if constexpr (RT <= 2) issue_piece(std::integral_constant<int, 2>{}, nstage);
+            if constexpr (RT <= 3) issue_piece(std::integral_constant<int, 3>{}, nstage);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      group(std::integral_constant<int, 0>{});
+      if constexpr (RT > 1) group(std::integral_constant<int, 1>{});
+      if constexpr (RT > 2) group(std::integral_constant<int, 2>{});
+      if constexpr (RT > 3) group(std::integral_constant<int, 3>{});
+      if constexpr (RT > 4) group(std::integral_constant<int, 4>{});
+      if (more) advance();
+      if (j == 0 && c + 2 < NCH && !JV_ABLATE(p, 8)) load_A(c + 2);      // behind this step's weight pieces (the wait counts above rely on it)
+    }
+  }
+
+  // ---- epilogue: the whole tile through ONE slab laid over the (now idle) weight ring -- a single chunk has nothing left to
+  // prefetch -- then 2 RT rows per wave, RT at a time so that their loads, reductions and transcendentals overlap.  (In 32-row
+  // passes through a slab of their own, two barriers each, the tail took 13 - 19 us of a 50 us launch.)
+  if (JV_ABLATE(p, 16)) return;
+  const bool mish = p.act == ACT_MISH;      // (uniform) the one activation the estimator uses here
+  rg_lds_barrier();      // every wave is done reading the ring
+  float* const slab = reinterpret_cast<float*>(rc_lds);
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) slab[(mt * 16 + kq * 4 + e) * RG_SLD + wave * 32 + nt * 16 + r16] = acc[mt][nt][e];
+  rg_lds_barrier();
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    constexpr int RPW = RT;      // rows per wave and group: the wave owns tile rows 2 RT wave ... 2 RT wave + 2 RT - 1
+    rg_f32x4 v[RPW], r[RPW], rv[RPW];
+    long mrow[RPW];
+    bool ok[RPW], keep[RPW], tracked[RPW];
+    unsigned seen[RPW];
+    int slot[RPW];
+#pragma unroll
+    for (int jj = 0; jj < RPW; ++jj) {
+      const int trow = wave * 2 * RT + ps * RT + jj;
+      mrow[jj] = (long)m0 + trow;
+      ok[jj] = mrow[jj] < p.M;
+      const int2 ri = rowinfo[trow];
+      slot[jj] = ri.y & (RI_KEEP - 1);
+      const float inv = ok[jj] ? __uint_as_float((unsigned)ri.x) : 0.f;      // 1 / the power of two its window rows were staged with
+      v[jj] = *reinterpret_cast<const rg_f32x4*>(slab + trow * RG_SLD + 4 * lane) * (cs4 * inv) + b4;
+      keep[jj] = ok[jj] && (ri.y & RI_KEEP) != 0;
+      r[jj] = (p.res && ok[jj]) ? *reinterpret_cast<const rg_f32x4*>(p.res + mrow[jj] * p.ldr + 4 * lane) : rg_f32x4{0.f, 0.f, 0.f, 0.f};
+      rv[jj] = (p.rowvec && ok[jj]) ? *reinterpret_cast<const rg_f32x4*>(p.rowvec + (long)slot[jj] * p.rowvec_ld + 4 * lane)
+                                    : rg_f32x4{0.f, 0.f, 0.f, 0.f};
+      tracked[jj] = ok[jj] && (ri.y & RI_TRACK) != 0;
+      seen[jj] = 0xffffffffu;
+      if (tracked[jj]) seen[jj] = *reinterpret_cast<const unsigned*>(p.amax_out + slot[jj]);
+    }
+    if (p.ln) {
+      float sum[RPW], sq[RPW];
+#pragma unroll
+      for (int jj = 0; jj < RPW; ++jj) sum[jj] = wave_sum((v[jj][0] + v[jj][1]) + (v[jj][2] + v[jj][3]));
+#pragma unroll
+      for (int jj = 0; jj < RPW; ++jj) {
+        const rg_f32x4 d = v[jj] - sum[jj] * (1.f / 256.f);
+        sq[jj] = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+      }
+#pragma unroll
+      for (int jj = 0; jj < RPW; ++jj) {
+        const float mean = sum[jj] * (1.f / 256.f);
+        const float rstd = 1.0f / sqrtf(sq[jj] * (1.f / 256.f) + p.ln_eps);
+        v[jj] = (v[jj] - mean) * rstd * gg + bb;
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < RPW; ++jj) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[jj][e] = keep[jj] ? (mish ? mish_fast(v[jj][e]) : act_apply(v[jj][e], p.act)) : 0.f;
+      v[jj] = (v[jj] + rv[jj]) + r[jj];
+      if (ok[jj]) *reinterpret_cast<rg_f32x4*>(p.out + mrow[jj] * p.ldo + 4 * lane) = v[jj];
+    }
+    if (p.amax_out) {
+#pragma unroll
+      for (int jj = 0; jj < RPW; ++jj) {
+        unsigned u = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u = max(u, __float_as_uint(v[jj][e]) & 0x7fffffffu);
+        if (tracked[jj] && __builtin_amdgcn_ballot_w64(u > seen[jj]) != 0) {
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o));
+          if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(p.amax_out + slot[jj]), u);
+        }
+      }
+    }
+  }
+  asm volatile("" ::"v"(warm));
+}
+
+}  // namespace jv

@@ -1,5 +1,5 @@
 // Host side of the row-owning fp16x3 GEMM (rowgemm_kernel.h): tile height choice and launch.
-#include "rowgemm_kernel.h"
+#include "rowconv_kernel.h"
 
 namespace jv {
 
@@ -58,6 +58,52 @@ int rowgemm_tile(int M) {
   }
   if (cdiv(M, 16 * best) < 96) return 0;
   return best;
+}
+
+namespace {
+template <int RT>
+int rc_launch(const RowConvArgs& a, hipStream_t st) {
+  static bool raised[64] = {};
+  int dev = 0;
+  JV_HIP(hipGetDevice(&dev));
+  if (!raised[dev & 63]) {
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowconv_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               rc_lds_bytes<RT>()));
+    raised[dev & 63] = true;
+  }
+  const bool prof = prof_on();
+  if (prof) prof_begin(st);
+  hipLaunchKernelGGL((rowconv_kernel<RT>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rc_lds_bytes<RT>(), st, a);
+  if (prof) {
+    static const std::string name = std::string("rowconv_h3<") + std::to_string(16 * RT) + "x256,k3>";
+    const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M);
+    const double bytes = 4.0 * (rows * a.Cin + 256.0 * 3 * a.Cin + rows * 256 * (a.res ? 2 : 1));
+    prof_end(st, name.c_str(), 2.0 * rows * 256.0 * 3 * a.Cin, bytes);
+  }
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+}  // namespace
+
+// causal k = 3 convolution to 256 channels with the row-wise tail in its epilogue (rowconv_kernel.h)
+int rowconv(const RowConvArgs& a, hipStream_t st) {
+  if (a.M <= 0) return JV_OK;
+  if (const char* ab = tuning_env("JV_RG_ABLATE")) const_cast<RowConvArgs&>(a).ablate = atoi(ab);
+  if (!a.A || !a.W2 || !a.colscale || !a.amax_in || !a.row_slot || !a.out)
+    return fail(JV_ERR_ARG, "rowconv: needs A, W planes, colscale, the measured bound with its row slots, and an output");
+  if ((a.Cin & 31) || a.Cin < 32 || (a.lda & 3) || (a.ldw & 7) || (a.ldo & 3) || (a.res && (a.ldr & 3)) || (a.rowvec && (a.rowvec_ld & 3)))
+    return fail(JV_ERR_ARG, "rowconv: Cin % 32 == 0 and aligned strides required");
+  if (a.ln && (!a.ln_g || !a.ln_b)) return fail(JV_ERR_ARG, "rowconv: LayerNorm needs gain and offset");
+  int rt = rowgemm_tile(a.M);
+  if (rt == 0) rt = 2;
+  switch (rt) {
+    case 1:
+    case 2: return rc_launch<2>(a, st);
+    case 3: return rc_launch<3>(a, st);
+    case 4: return rc_launch<4>(a, st);
+    case 5: return rc_launch<5>(a, st);
+    default: return fail(JV_ERR_ARG, "rowconv: bad tile height");
+  }
 }
 
 int rowgemm(const RowGemmArgs& a, int epi, hipStream_t st) {

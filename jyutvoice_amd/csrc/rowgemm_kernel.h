@@ -206,6 +206,13 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const RowGemmArgs p) {
   if (total > 1) issue_all(1);
   int s = 0;
   for (int c = 0; c < NC; ++c) {
+    // the epilogue's per-column constants of this chunk, requested before its main loop so that their latency is not paid
+    // behind it
+    const int n0 = c * 256 + 4 * lane;      // this lane's four columns in the row pass
+    rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.colscale + n0);
+    cs4 = cs4 * (1.0f / p.a_scale);        // powers of two: exact
+    rg_f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) b4 = *reinterpret_cast<const rg_f32x4*>(p.bias + n0);
 #pragma unroll
     for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
@@ -262,34 +269,18 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const RowGemmArgs p) {
     }
 
     // ---- epilogue of chunk c: 32 rows at a time through the slab (its own LDS region: the ring keeps streaming) ----
-    const int n0 = c * 256 + 4 * lane;      // this lane's four columns in the row pass
-    rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.colscale + n0);
-    cs4 = cs4 * (1.0f / p.a_scale);        // powers of two: exact
-    rg_f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) b4 = *reinterpret_cast<const rg_f32x4*>(p.bias + n0);
-#pragma unroll
-    for (int ps = 0; ps < (RT + 1) / 2; ++ps) {
-#pragma unroll
-      for (int ml = 0; ml < 2; ++ml) {
-        if (2 * ps + ml < RT) {
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              slab[(ml * 16 + kq * 4 + e) * RG_SLD + wave * 32 + nt * 16 + r16] = acc[2 * ps + ml][nt][e];
-        }
-      }
-      rg_lds_barrier();
-      constexpr int RPW = RG_SLAB_ROWS / 8;      // rows per wave and pass
+    // the rows [trow0, trow0 + RPW) of the tile, held in slab rows [srow0, ...) of `sl`, one wave per row
+    auto rows_body = [&](auto rpw_tag, const float* sl, const int trow0, const int srow0) {
+      constexpr int RPW = decltype(rpw_tag)::value;
       rg_f32x4 v[RPW];
       long mrow[RPW];
       bool ok[RPW];
 #pragma unroll
       for (int j = 0; j < RPW; ++j) {
-        const int trow = ps * 32 + wave * RPW + j;
+        const int trow = trow0 + j;
         mrow[j] = (long)m0 + trow;
         ok[j] = trow < R && mrow[j] < p.M;
-        v[j] = *reinterpret_cast<const rg_f32x4*>(slab + (wave * RPW + j) * RG_SLD + 4 * lane) * cs4 + b4;
+        v[j] = *reinterpret_cast<const rg_f32x4*>(sl + (srow0 + j) * RG_SLD + 4 * lane) * cs4 + b4;
       }
       if constexpr (EPI == RG_PLAIN) {
 #pragma unroll
@@ -387,7 +378,39 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const RowGemmArgs p) {
           }
         }
       }
-      rg_lds_barrier();      // the slab is rewritten by the next pass / chunk
+    };
+    if constexpr (EPI == RG_RES || EPI == RG_RES_LN) {
+      // one 256-column chunk: nothing left to prefetch, so the whole tile goes through ONE slab laid over the idle ring and
+      // every wave takes its 2 RT rows RT at a time (loads, reductions and conversions of RT rows overlap).  In 32-row passes
+      // through the small slab, two barriers each, this tail was 10 us of a 44 us launch.
+      rg_lds_barrier();      // every wave is done reading the ring
+      float* const big = reinterpret_cast<float*>(rg_lds);
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) big[(mt * 16 + kq * 4 + e) * RG_SLD + wave * 32 + nt * 16 + r16] = acc[mt][nt][e];
+      rg_lds_barrier();
+      rows_body(std::integral_constant<int, RT>{}, big, wave * 2 * RT, wave * 2 * RT);
+      rows_body(std::integral_constant<int, RT>{}, big, wave * 2 * RT + RT, wave * 2 * RT + RT);
+    } else {
+#pragma unroll
+      for (int ps = 0; ps < (RT + 1) / 2; ++ps) {
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml) {
+          if (2 * ps + ml < RT) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                slab[(ml * 16 + kq * 4 + e) * RG_SLD + wave * 32 + nt * 16 + r16] = acc[2 * ps + ml][nt][e];
+          }
+        }
+        rg_lds_barrier();
+        rows_body(std::integral_constant<int, RG_SLAB_ROWS / 8>{}, slab, ps * 32 + wave * (RG_SLAB_ROWS / 8), wave * (RG_SLAB_ROWS / 8));
+        rg_lds_barrier();      // the slab is rewritten by the next pass / chunk
+      }
     }
   }
   asm volatile("" ::"v"(warm));      // the warm-up load is waited for here, not before

@@ -319,6 +319,19 @@ def op_attention_planes(qkv, lens, B, G, S, L, bounds=None, chunk=0, planes_out=
     return out
 
 
+def op_rowconv(A, W, bias=None, ln=None, act="none", rowmask=None, rowvec=None, res=None, amax_in=None, amax_out=None):
+    """rowconv_kernel.h: causal k = 3 conv to 256 channels + LayerNorm / act / mask / + rowvec / + res; W [256, 3 * Cin]"""
+    lib = _lib.load()
+    rows, cin = A.shape
+    out = torch.empty(rows, 256, device=A.device)
+    g, b = (ln if ln is not None else (None, None))
+    if amax_in is None:
+        amax_in = A.abs().max().reshape(1)
+    check(lib.jv_op_rowconv(_ptr(A), rows, rows, cin, _ptr(W), _ptr(bias), _ptr(g), _ptr(b), _lib.ACT[act], _ptr(rowmask),
+                            _ptr(rowvec), _ptr(res), _ptr(amax_in), _ptr(amax_out), _ptr(out), _stream(A.device)))
+    return out
+
+
 def op_layernorm(x, g, b, eps=1e-5):
     lib = _lib.load()
     out = torch.empty_like(x)

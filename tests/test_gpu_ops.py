@@ -557,3 +557,38 @@ def test_attention_planes(dev, B, L, lens):
     for i in range(10):
         noise.normal_()
         assert torch.equal(op_attention_planes(qkv.to(dev), lens_t.to(dev), B, G, S, L, bounds), first), i
+
+
+@pytest.mark.parametrize("rt", ["2", "3", "5"])
+@pytest.mark.parametrize("cin", [256, 512, 64])
+def test_rowconv(dev, monkeypatch, rt, cin):
+    """rowconv_kernel.h: the estimator's causal k = 3 convolution with its row-wise tail in the epilogue, against fp64:
+    conv -> LayerNorm -> Mish -> mask -> + time-embedding vector -> + residual (CausalBlock1D + the resnet's additions,
+    decoder.py:110-115, 784-788), the bare convolution (down / up convs), the tracked maximum, and the DMA-ring race screen"""
+    from jyutvoice_amd.engine import op_rowconv
+    monkeypatch.setenv("JV_ROWGEMM_RT", rt)
+    g = torch.Generator().manual_seed(int(rt) * 100 + cin)
+    rows = 1500 + 11 * int(rt)
+    A = torch.randn(rows, cin, generator=g) * 2.5
+    w = torch.randn(256, cin, 3, generator=g) / math.sqrt(3 * cin)
+    b = torch.randn(256, generator=g) * 0.1
+    lg, lb = 1 + 0.1 * torch.randn(256, generator=g), 0.1 * torch.randn(256, generator=g)
+    mask = (torch.rand(rows, generator=g) > 0.2).to(torch.uint8)
+    res = torch.randn(rows, 256, generator=g)
+    vec = torch.randn(256, generator=g)
+    slot = torch.zeros(1, device=dev)
+    out = op_rowconv(A.to(dev), pack_conv(w).to(dev), b.to(dev), ln=(lg.to(dev), lb.to(dev)), act="mish", rowmask=mask.to(dev),
+                     rowvec=vec.to(dev), res=res.to(dev), amax_out=slot)
+    z = conv_rows_ref(A * mask[:, None], w, b, -2, 1)
+    z = F.layer_norm(z, (256,), lg.double(), lb.double(), 1e-5)
+    want = F.mish(z) * mask[:, None].double() + vec.double() + res.double()
+    assert float((out.double().cpu() - want).abs().max()) < 2e-5
+    assert float(slot) == float(out[mask.bool().to(dev)].abs().max())          # masked rows are not tracked
+    # the bare convolution, bound well above the data (a stale maximum from an earlier, larger state of the buffer)
+    plain = op_rowconv(A.to(dev), pack_conv(w).to(dev), b.to(dev), amax_in=torch.tensor([40.0], device=dev))
+    want = conv_rows_ref(A, w, b, -2, 1)
+    assert float((plain.double().cpu() - want).abs().max()) < 2e-6 * float(want.abs().max()) * 8
+    noise = torch.empty(64 << 20, device=dev)
+    for i in range(10):
+        noise.normal_()
+        assert torch.equal(op_rowconv(A.to(dev), pack_conv(w).to(dev), b.to(dev), amax_in=torch.tensor([40.0], device=dev)), plain), i

@@ -15,7 +15,7 @@ os.environ.setdefault("JV_DYNAMIC_ENV", "1")
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from jyutvoice_amd.engine import op_attention_planes, op_attention, op_attention_h3, op_conv_gemm, op_linear_h3, op_rowgemm  # noqa: E402
+from jyutvoice_amd.engine import op_attention_planes, op_attention, op_attention_h3, op_conv_gemm, op_linear_h3, op_rowconv, op_rowgemm  # noqa: E402
 
 dev = torch.device("cuda:0")
 M = int(os.environ.get("JV_M", 4 + 64 * 304))
@@ -49,7 +49,12 @@ for name, cin, n, taps, ln in shapes:
     if ln:
         kw["ln"] = (torch.ones(n, device=dev), torch.zeros(n, device=dev))
         kw["act"] = "mish"
-    if os.environ.get("JV_OP_ROWGEMM") and taps == 1 and not ln and n % 256 == 0:      # row-owning fp16x3 GEMM (rowgemm_kernel.h)
+    if os.environ.get("JV_OP_ROWCONV") and taps == 3 and n == 256:      # row-owning causal conv (rowconv_kernel.h)
+        A = A[:M].contiguous()
+        bound = A.abs().max().reshape(1)
+        kw3 = dict(ln=kw["ln"], act="mish") if ln else {}
+        t = timeit(lambda: op_rowconv(A, W, b, amax_in=bound, **kw3))
+    elif os.environ.get("JV_OP_ROWGEMM") and taps == 1 and not ln and n % 256 == 0:      # row-owning fp16x3 GEMM (rowgemm_kernel.h)
         A = A[:M].contiguous()
         epi = os.environ.get("JV_ROWGEMM_EPI", "plain")
         kw2 = {}

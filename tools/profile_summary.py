@@ -12,12 +12,21 @@ out = sys.argv[1]
 
 
 def short(name):
+    """rocprofv3 kernel name -> the name bench.py's in-library profiler gives the same launches"""
+    m = re.search(r"rowgemm_kernel<(\d+), (\d+)>", name)
+    if m:
+        epi = {"0": "", "1": ",gelu", "2": ",res", "3": ",res,ln", "4": ",qkv"}.get(m.group(2), "")
+        return f"rowgemm_h3<{16 * int(m.group(1))}x256{epi}>"
+    m = re.search(r"attn64_pl_kernel<(\d)>", name)
+    if m:
+        return f"attn64_pl<{m.group(1)} waves>"
     m = re.search(r"conv_gemm_x6_kernel<(\d+), (\d+), \d+, \d+, (\d), (\d), (\d)(?:, (\d+))?(?:, (\d+))?>", name)
     if m:
         pro = {"0": "", "1": ",snake", "2": ",lrelu"}[m.group(3)]
-        epi = {"0": "", "1": ",gelu", "2": ",res", "4": ",generic"}.get(m.group(4), "")
+        epi = {"0": "", "1": ",gelu", "9": ",gelu", "2": ",res", "4": ",generic"}.get(m.group(4), "")
+        dma = ",dmaA" if m.group(5) == "3" else ""
         fam = "conv_gemm_h3" if m.group(7) == "2" else "conv_gemm_x6"      # last parameter: planes per operand
-        return f"{fam}<{m.group(1)}x{m.group(2)}{pro}{epi}>"
+        return f"{fam}<{m.group(1)}x{m.group(2)}{pro}{dma}{epi}>"
     m = re.search(r"conv_gemm_kernel<(\d+), (\d+), \d+, \d+, \d+, (\d), (\d)>", name)
     if m:
         pro = {"0": "", "1": ",snake", "2": ",lrelu"}[m.group(3)]
