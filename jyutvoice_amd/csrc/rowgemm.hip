@@ -45,8 +45,8 @@ int rg_launch1(const RowGemmArgs& a, int epi, hipStream_t st) {
 }  // namespace
 
 // tile height (in 16-row units) for M rows: the fewest rounds of workgroups over the 256 CUs times the rows each round
-// costs; ties go to the taller tile (each weight byte is then used for more rows).  0: too few rows for one workgroup per
-// CU to pay (the tile kernels split N as well and keep more CUs busy).
+// costs; ties go to the taller tile (each weight byte is then used for more rows).  0: use the tile kernels -- too few rows
+// for one workgroup per CU to pay (the tile kernels split N as well and keep more CUs busy), or more than one round of them.
 int rowgemm_tile(int M) {
   if (const char* f = dyn_env("JV_ROWGEMM_RT")) return atoi(f);
   int best = 0;
@@ -56,7 +56,11 @@ int rowgemm_tile(int M) {
     const long cost = cdivl(wgs, 256) * rt;
     if (!best || cost < best_cost || (cost == best_cost && rt > best)) { best = rt; best_cost = cost; }
   }
-  if (cdiv(M, 16 * best) < 96) return 0;
+  // measured on the whole path (bench.py, same box, against the tile kernels): 32 utterances x 300 frames (244 workgroups, one
+  // round) -6.3 %, 16 utterances -2.7 %, 8 utterances and 8 x 512 frames a tie, 64 utterances (487 workgroups, two rounds)
+  // +3 %: past one round the tile kernels' many small tiles balance better than two rounds of whole-CU workgroups
+  const int wgs = cdiv(M, 16 * best);
+  if (wgs < 96 || wgs > 256) return 0;
   return best;
 }
 
