@@ -99,6 +99,7 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   c.exact_range = getenv("JV_EXACT_RANGE") != nullptr;
   c.dma_a = getenv("JV_DMA_A") != nullptr;
   c.no_rowgemm = getenv("JV_NO_ROWGEMM") != nullptr;
+  c.no_splitk = getenv("JV_NO_SPLITK") != nullptr;
   c.rg_ff1 = getenv("JV_RG_FF1") != nullptr;
   c.no_attn_planes = getenv("JV_NO_ATTN_PLANES") != nullptr;
   c.max_frames = max_frames;

@@ -242,13 +242,20 @@ __global__ __launch_bounds__(256, (BM == 64 && BN == 64 && PRO == PRO_NONE && EP
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
 
-  const int nchunks = p.Cin >> 5;
-  const int nsteps = nchunks * ntaps;
-  if constexpr (APL) dma_A(0, 0);
-  else load_A(0);
-  if constexpr (NWB == 2) dma_W(0, 0);
+  // split-K (ConvGemmArgs::ksplit): this workgroup contracts the chunks [c_lo, c_hi) and writes its own partial
+  int c_lo = 0, c_hi = p.Cin >> 5;
+  if (p.ksplit > 1) {
+    const int z = blockIdx.y, nch = p.Cin >> 5;
+    c_lo = z * nch / p.ksplit;
+    c_hi = (z + 1) * nch / p.ksplit;
+    out += (long)z * p.split_stride;
+  }
+  const int nsteps = (c_hi - c_lo) * ntaps;
+  if constexpr (APL) dma_A(c_lo * 32, 0);
+  else load_A(c_lo * 32);
+  if constexpr (NWB == 2) dma_W(c_lo * 32, 0);
   if (JV_STAMP(p)) t_loop = __builtin_amdgcn_s_memtime();
-  int c = 0, j = 0;
+  int c = c_lo, j = 0;
   for (int s = 0; s < nsteps; ++s) {
     if (!JV_ABLATE(p, 4)) __syncthreads();      // every wave is done reading the previous step's LDS images
     if constexpr (NWB == 1) dma_W(j * p.Cin + c * 32, 0);
@@ -380,7 +387,8 @@ int x6_launch4(const ConvGemmArgs& a_in, hipStream_t st) {
     }
     return JV_OK;
   }
-  hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, NWB, NP>), dim3(tiles_m * tiles_n), dim3(256), lds, st, a, tiles_n);
+  hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, NWB, NP>), dim3(tiles_m * tiles_n, a.ksplit > 1 ? a.ksplit : 1),
+                     dim3(256), lds, st, a, tiles_n);
   if (prof) {
     static const std::string name = std::string(NP == 2 ? "conv_gemm_h3<" : "conv_gemm_x6<") + std::to_string(BM) + "x" + std::to_string(BN) +
                                     (PRO == PRO_SNAKE ? ",snake" : PRO == PRO_LRELU ? ",lrelu" : "") +

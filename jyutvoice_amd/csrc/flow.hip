@@ -8,6 +8,7 @@
 // caller's stream with no host synchronisation (graph-capturable).
 #include <math.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "jv_model.h"
@@ -22,6 +23,7 @@ int rowgemm_tile(int M);
 
 constexpr int FLOW_G = 4;      // leading guard rows (>= causal left context 2)
 constexpr int FLOW_GAP = 4;    // rows between utterances
+constexpr int PARTIAL_ROWS = 2048, PARTIAL_SPLITS = 8;      // split-K is for short M only (estimator_body)
 
 struct FlowWs {
   long rows_alloc = 0;      // rows every [*,C] buffer below can hold
@@ -37,6 +39,7 @@ struct FlowWs {
   // in the batch and however a batch is sharded over GPUs.  Zeroed once per solve.
   float* amax = nullptr;
   int amax_stride = 0;      // floats per buffer = 2 * max_batch
+  float* partial = nullptr;      // [8][PARTIAL_ROWS][256] split-K partial sums (short M only)
   float *d = nullptr;                                                 // [rows,80]
   float *tsin = nullptr, *t1 = nullptr, *tmish = nullptr, *temb = nullptr;
   float *t_dev = nullptr, *t_table = nullptr, *dt_table = nullptr;
@@ -79,6 +82,7 @@ int flow_ws_create(Context& c) {
   JV_TRY(F(&w->att, R * 512));
   JV_TRY(F(&w->ff, R * 1024));
   JV_TRY(F(&w->d, R * 80));
+  JV_TRY(F(&w->partial, (size_t)PARTIAL_SPLITS * PARTIAL_ROWS * 256));
   JV_TRY(F(&w->tsin, (size_t)B2 * 320));
   JV_TRY(F(&w->t1, (size_t)B2 * 1024));
   JV_TRY(F(&w->tmish, (size_t)B2 * 1024));
@@ -194,10 +198,36 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.W2 = m.w2; a.w2_plane = (long)m.n_rows * m.ldw; a.colscale = m.colscale; a.amax_in = slots_of(a.A); a.a_extra = 0.f;
     amax_geo(a);
   };
+  // ---- short M (a single utterance: 268 rows = 20 tiles of 64x64): the K = 512 ... 1536 contractions to 256 channels are
+  // split over ksplit workgroups per tile (ConvGemmArgs::ksplit) and one row-wise kernel sums the partials and runs the
+  // whole tail -- bias, LayerNorm / Mish / mask, time embedding, residual, tracking, and the LayerNorm that feeds the next
+  // GEMM (splitk_reduce_rows).  Traced at B = 1: ff.net.2 + its LayerNorm 20.8 + 4.8 us -> 2 x ~5.
+  // The split is a function of K alone (PARTIAL_SPLITS shares of the chunks whenever M <= PARTIAL_ROWS), never of M: the
+  // grouping of a row's partial sums must not depend on how many rows the batch has, or a shard would no longer reproduce
+  // the whole batch bit for bit (tests/test_gpu_dist.py).
+  const int ksplit = (!c.no_splitk && g.M <= PARTIAL_ROWS) ? PARTIAL_SPLITS : 1;
+  // `a`: the full-semantics launch (N = 256); ln2 / out2: optional LayerNorm of the stored row for the next GEMM
+  auto splitk = [&](const ConvGemmArgs& a, const LnW* ln2, float* out2) -> int {
+    ConvGemmArgs p = a;
+    p.ln = 0; p.act = ACT_NONE; p.bias = nullptr; p.rowmask_out = nullptr; p.rowvec = nullptr; p.row_sample = nullptr;
+    p.res1 = nullptr; p.amax_out = nullptr;
+    p.out = w.partial; p.ldo = 256;
+    p.ksplit = std::min(ksplit, a.Cin >> 5); p.split_stride = (long)a.M * 256;
+    JV_TRY(conv_gemm(p, 1, st));
+    SplitKReduceArgs r{};
+    r.partial = w.partial; r.ksplit = p.ksplit; r.split_stride = p.split_stride; r.rows = a.M;
+    r.bias = a.bias; r.ln = a.ln; r.ln_g = a.ln_g; r.ln_b = a.ln_b; r.ln_eps = a.ln_eps; r.act = a.act;
+    r.rowmask = a.rowmask_out; r.rowvec = a.rowvec; r.row_sample = w.row_sample; r.rowvec_ld = a.rowvec_ld;
+    r.res = a.res1; r.ldr = a.ldr1; r.out = a.out; r.ldo = a.ldo;
+    r.amax_out = a.amax_out; r.amax_mask = a.amax_mask;
+    if (ln2) { r.ln2_g = ln2->g; r.ln2_b = ln2->b; r.out2 = out2; }
+    return splitk_reduce_rows(r, st);
+  };
   // A causal k = 3 convolution of a trunk buffer: on the row-owning kernel (rowconv_kernel.h: LayerNorm / Mish / mask / time
   // embedding / residual in its epilogue, no ln_epilogue_rows pass) when the batch fills the chip, else on the tile kernels
   const bool use_rc = !c.exact_range && !c.no_rowgemm && rowgemm_tile((int)g.M) > 0;
   auto conv3 = [&](ConvGemmArgs& a, const GemmW& m) -> int {
+    if (ksplit > 1 && a.N == 256 && !a.res2 && (m.w3 || m.w2)) return splitk(a, nullptr, nullptr);
     if (!use_rc || !a.amax_in || !m.w2 || a.ntaps != 3 || a.tap_row0 != -2 || a.N != 256 || a.ldo != 256 && a.ldo != 512)
       return conv_gemm(a, 1, st);
     RowConvArgs r{};
@@ -251,8 +281,9 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     if (pre(m)) return layernorm256_planes(h, reinterpret_cast<unsigned short*>(w.ln), R * 256, m.a_scale, n.g, n.b, 1e-5f, g.M, st);
     return layernorm_rows(h, nullptr, w.ln, n.g, n.b, 1e-5f, g.M, 256, nullptr, st);
   };
-  auto btb = [&](const BtbW& b, float* h, float* out, int ldo) -> int {
-    JV_TRY(ln_to(b.n1, b.qkv, h));
+  auto btb = [&](const BtbW& b, const BtbW* next, bool ln_ready, float* h, float* out, int ldo) -> int {
+    const bool sk = ksplit > 1 && !c.dma_a;      // split-K tails also write the next LayerNorm (fp32 rows) into w.ln
+    if (!(sk && ln_ready)) JV_TRY(ln_to(b.n1, b.qkv, h));
     ConvGemmArgs a = base_args(g, w.ln, 256, b.qkv, w.qkv, 1536);
     h3(a, b.qkv);
     if (pre(b.qkv)) planes_in(a, w.ln, 256);
@@ -269,8 +300,12 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     track(a);      // -> h
     h3(a, b.out);
     if (pre(b.out)) planes_in(a, w.att, 512);
-    JV_TRY(conv_gemm(a, 1, st));
-    JV_TRY(ln_to(b.n3, b.ff1, h));
+    if (sk) {
+      JV_TRY(splitk(a, &b.n3, w.ln));      // h += to_out(att); ln = LayerNorm3(h)
+    } else {
+      JV_TRY(conv_gemm(a, 1, st));
+      JV_TRY(ln_to(b.n3, b.ff1, h));
+    }
     a = base_args(g, w.ln, 256, b.ff1, w.ff, 1024);
     a.act = ACT_GELU;
     h3(a, b.ff1);
@@ -285,6 +320,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     track(a);      // -> h / cat
     h3(a, b.ff2);
     if (ff_planes) planes_in(a, w.ff, 1024);
+    if (sk) return splitk(a, (next && out == h) ? &next->n1 : nullptr, w.ln);      // + the next block's norm1
     return conv_gemm(a, 1, st);
   };
   // ---- the same block on the row-owning GEMM (rowgemm_kernel.h) when the batch fills the chip: every linear takes its A
@@ -370,7 +406,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     for (int j = 0; j < EST_NBLK; ++j) {
       const bool last = j == EST_NBLK - 1;
       if (all) JV_TRY(btb_rg(blk[j], last ? nullptr : &blk[j + 1], j > 0, h, last ? last_out : h, last ? last_ldo : 256));
-      else JV_TRY(btb(blk[j], h, last ? last_out : h, last ? last_ldo : 256));
+      else JV_TRY(btb(blk[j], last ? nullptr : &blk[j + 1], j > 0, h, last ? last_out : h, last ? last_ldo : 256));
     }
     return JV_OK;
   };

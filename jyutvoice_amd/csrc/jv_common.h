@@ -107,6 +107,12 @@ struct ConvGemmArgs {
   // per output row): rows with 0 are padding whose values never reach a real frame and are left out of amax_out.
   int amax_G, amax_S, amax_nb;
   const unsigned char* amax_mask;
+  // split-K for short M (flow.hip: a single utterance is 20 tiles of 64x64 x 32 dependent K steps otherwise): grid.y = ksplit
+  // workgroups per tile each contract a contiguous share of the 32-channel chunks and write a plain fp32 partial to
+  // out + y * split_stride (the caller points `out` at a partial-sum workspace and leaves bias / epilogue to
+  // splitk_reduce_rows); 0 / 1 = off
+  int ksplit;
+  long split_stride;
   int rowtab_off;      // set by the launcher: byte offset of the tile's per-row table in dynamic LDS (conv_gemm_epilogue.h)
   // optional with W2 (linears, ntaps = 1): A already split by its producer -- two fp16 planes [2][a_rows][lda2] of
   // A * a_scale (LayerNorm, attention and the GELU epilogue write them, same bytes as the fp32 rows); both operands then
@@ -197,6 +203,20 @@ int attention64_planes(const AttnArgs& a, hipStream_t st);
 // out = LayerNorm_C(x (+ add)) * g + b, optional ReLU, rows with rowmask_out == 0 written as zero
 int layernorm_rows(const float* x, const float* add, float* out, const float* g, const float* b, float eps, long rows,
                    int C, const unsigned char* rowmask_out, hipStream_t st, int relu = 0);
+// out = tail(sum_z partial[z] + bias), tail = [LayerNorm -> act -> mask] -> + rowvec[sample] -> + res, tracked like
+// ln_epilogue_rows; optionally a second LayerNorm of the stored row -> out2 (the next GEMM's input).  256 columns.
+struct SplitKReduceArgs {
+  const float* partial; int ksplit; long split_stride; long rows;
+  const float* bias;
+  int ln; const float *ln_g, *ln_b; float ln_eps; int act;
+  const unsigned char* rowmask;
+  const float* rowvec; const int* row_sample; int rowvec_ld;
+  const float* res; long ldr;
+  float* out; long ldo;
+  float* amax_out; const unsigned char* amax_mask;      // slot = row_sample[row]
+  const float *ln2_g, *ln2_b; float* out2;              // optional: LayerNorm_256(out row) -> out2 [rows, 256]
+};
+int splitk_reduce_rows(const SplitKReduceArgs& a, hipStream_t st);
 int layernorm256_planes(const float* x, unsigned short* out2, long plane, float scale, const float* g, const float* b, float eps,
                         long rows, hipStream_t st);
 

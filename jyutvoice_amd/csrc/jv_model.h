@@ -131,6 +131,7 @@ struct Context {
                                  // in the pipeline than the in-kernel split; kept as a tested alternative)
   bool rg_ff1 = false;           // JV_RG_FF1=1: ff.net.0 on the row-owning GEMM too (default: tile kernel, measured faster)
   bool no_attn_planes = false;   // JV_NO_ATTN_PLANES=1: attention splits K / V itself (attention.hip) instead of taking planes
+  bool no_splitk = false;        // JV_NO_SPLITK=1: no split-K at short M (A/B aid)
   bool no_rowgemm = false;       // JV_NO_ROWGEMM=1: keep the transformer linears on the tile kernels at every batch size (A/B aid)
   bool exact_range = false;      // true: bf16x6 everywhere (jv_flow_set_contraction); false: fp16x3 where the range is proven
   bool step_graphs = false;      // replay the Euler step as a captured hipGraph (jv_flow_set_graph; never under the profiler)

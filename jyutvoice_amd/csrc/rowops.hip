@@ -231,6 +231,68 @@ int ln_epilogue_rows(float* x, const float* g, const float* b, float eps, long r
   return JV_OK;
 }
 
+// ---- split-K tail (short M): sum of the partials + everything row-wise that follows the GEMM ---------------------------
+// One wave per row of 256 columns.  With few rows (a single utterance) the K = 512 ... 1536 contractions of the estimator are
+// 20 workgroups x up to 48 dependent K steps; split over 4 ... 8 workgroups per tile they finish in a few steps each, and this
+// kernel does what their epilogues did (bias, LayerNorm -> Mish -> mask, time embedding, residual, bound tracking) AND the
+// LayerNorm that feeds the next GEMM -- one launch where round 1 had the long GEMM plus a LayerNorm launch.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitKReduceArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const float* src = a.partial + row * 256 + 4 * lane;
+  f32x4 v = *reinterpret_cast<const f32x4*>(src);
+  for (int z = 1; z < a.ksplit; ++z) v += *reinterpret_cast<const f32x4*>(src + (long)z * a.split_stride);      // fixed order: deterministic
+  if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + 4 * lane);
+  const int sample = a.row_sample ? a.row_sample[row] : 0;
+  float* slot = a.amax_out ? a.amax_out + sample : nullptr;
+  const unsigned seen = slot ? *reinterpret_cast<const unsigned*>(slot) : 0xffffffffu;
+  const bool keep = !a.rowmask || a.rowmask[row] != 0;
+  if (a.ln) {
+    const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.f / 256.f);
+    const f32x4 d = v - mean;
+    const float rstd = 1.0f / sqrtf(wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.f / 256.f) + a.ln_eps);
+    v = d * rstd * *reinterpret_cast<const f32x4*>(a.ln_g + 4 * lane) + *reinterpret_cast<const f32x4*>(a.ln_b + 4 * lane);
+  }
+  if (a.ln || a.act != ACT_NONE || a.rowmask) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = keep ? act_apply(v[e], a.act) : 0.f;
+  }
+  if (a.rowvec) v += *reinterpret_cast<const f32x4*>(a.rowvec + (long)sample * a.rowvec_ld + 4 * lane);
+  if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + row * a.ldr + 4 * lane);
+  *reinterpret_cast<f32x4*>(a.out + row * a.ldo + 4 * lane) = v;
+  if (slot && (!a.amax_mask || a.amax_mask[row] != 0)) {
+    unsigned u = 0u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) u = max(u, __float_as_uint(v[e]) & 0x7fffffffu);
+    if (__builtin_amdgcn_ballot_w64(u > seen) != 0) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o));
+      if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(slot), u);
+    }
+  }
+  if (a.out2) {
+    const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.f / 256.f);
+    const f32x4 d = v - mean;
+    const float rstd = 1.0f / sqrtf(wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.f / 256.f) + 1e-5f);
+    *reinterpret_cast<f32x4*>(a.out2 + row * 256 + 4 * lane) =
+        d * rstd * *reinterpret_cast<const f32x4*>(a.ln2_g + 4 * lane) + *reinterpret_cast<const f32x4*>(a.ln2_b + 4 * lane);
+  }
+}
+
+int splitk_reduce_rows(const SplitKReduceArgs& a, hipStream_t st) {
+  if (a.rows <= 0) return JV_OK;
+  if (!a.partial || a.ksplit < 1 || !a.out || (a.ldo & 3) || (a.res && (a.ldr & 3)) || (a.rowvec && (a.rowvec_ld & 3)) ||
+      (a.ln && (!a.ln_g || !a.ln_b)) || (a.out2 && (!a.ln2_g || !a.ln2_b)))
+    return fail(JV_ERR_ARG, "splitk_reduce_rows: bad arguments");
+  const bool prof = prof_on();
+  if (prof) prof_begin(st);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivl(a.rows, 4)), dim3(256), 0, st, a);
+  if (prof) prof_end(st, "splitk_reduce", 0.0, 4.0 * a.rows * 256 * (a.ksplit + 1 + (a.res ? 1 : 0) + (a.out2 ? 1 : 0)));
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
 // ---- row metadata: rowmask[r] (1 = real frame) and row_sample[r] (utterance index) -----------------
 __global__ void row_meta_kernel(unsigned char* rowmask, int* row_sample, const int* lens, int nb, int reps, int G, int S,
                                 int L, long rows, int mul, int add) {

@@ -4,8 +4,12 @@ Two fresh processes (one per rank, as `torch.distributed.run` starts them; rende
 synthesise their contiguous shard of an 8-utterance ragged batch and all-gather the mels; the gathered result must equal
 the single-process synthesis of the whole batch BIT FOR BIT -- the measured fp16x3 bounds are per utterance and every
 kernel sums a row in the same order wherever the row sits, so an utterance's result does not depend on how the batch is
-sharded (the shards and the whole batch here run the same kernel set; a batch large enough for the row-owning GEMM against
-a shard too small for it agrees to rounding instead: test_gpu_pipeline.py::test_full_size_batch_invariance)."""
+sharded.  That holds while the shards and the whole batch run the same kernel set, which the engine picks from the batch's
+row count M = 2 B (T + 4) + 4 (split-K below 2049 rows, the row-owning GEMM once its grid fills the chip, the
+tile kernels between): the first case keeps both sides under the split-K limit, the second puts the whole batch above it
+and the shards below, where a row's K sum is grouped differently and the agreement is to rounding (<= 2e-5) -- as for
+test_gpu_pipeline.py::test_full_size_batch_invariance.  The benchmarked data-parallel job is weak-scaling (every rank runs
+the same 32 x 300 batch as the one-GPU job), so there every rank is in the one-GPU regime."""
 import os
 import socket
 import subprocess
@@ -27,12 +31,13 @@ def _free_port():
     return p
 
 
-def test_two_rank_shards_equal_single_process(tmp_path, tts_sd):
+@pytest.mark.parametrize("tokens,same_kernels", [(10, True), (24, False)])
+def test_two_rank_shards_equal_single_process(tmp_path, tts_sd, tokens, same_kernels):
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
     import jyutvoice_amd
     from jyutvoice_amd import synth
-    utts, tokens, steps = 8, 24, 3
+    utts, steps = 8, 3
     out = str(tmp_path / "gathered.pt")
     port = _free_port()
     procs = []
@@ -62,4 +67,9 @@ def test_two_rank_shards_equal_single_process(tmp_path, tts_sd):
     assert torch.equal(got["lens"], res["mel_lengths"].cpu())
     want = res["mel"].cpu()
     assert got["mel"].shape == want.shape
-    assert torch.equal(got["mel"], want), float((got["mel"] - want).abs().max())
+    rows = 2 * utts * (want.shape[-1] + 4) + 4
+    assert (rows <= 2048) == same_kernels, ("the case no longer sits on the side of the split-K limit it was sized for", rows)
+    if same_kernels:
+        assert torch.equal(got["mel"], want), float((got["mel"] - want).abs().max())
+    else:
+        assert float((got["mel"] - want).abs().max()) <= 2e-5
