@@ -100,7 +100,7 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   c.dma_a = getenv("JV_DMA_A") != nullptr;
   c.no_rowgemm = getenv("JV_NO_ROWGEMM") != nullptr;
   c.no_splitk = getenv("JV_NO_SPLITK") != nullptr;
-  c.rg_ff1 = getenv("JV_RG_FF1") != nullptr;
+  c.rg_ff1 = getenv("JV_TILE_FF1") == nullptr;
   c.no_attn_planes = getenv("JV_NO_ATTN_PLANES") != nullptr;
   c.max_frames = max_frames;
   c.max_tokens = max_tokens;
@@ -310,7 +310,7 @@ int jv_op_linear_h3(const float* A, int64_t rows, int M, int K, const float* W, 
   static void* scratch = nullptr;
   static size_t cap = 0;
   const size_t n = (size_t)N * K;
-  const size_t need = n * 4 + (size_t)N * 12 + 256;
+  const size_t need = n * 8 + (size_t)N * 12 + 512;
   if (need > cap) {
     if (scratch) (void)hipFree(scratch);
     JV_HIP(hipMalloc(&scratch, need));
@@ -414,7 +414,7 @@ int jv_op_rowgemm(const float* A, int64_t rows, int M, int K, const float* W, in
   static void* scratch = nullptr;
   static size_t cap = 0;
   const size_t n = (size_t)N * K;
-  const size_t need = n * 4 + (size_t)N * 12 + 256;
+  const size_t need = n * 8 + (size_t)N * 12 + 512;
   if (need > cap) {
     if (scratch) (void)hipFree(scratch);
     JV_HIP(hipMalloc(&scratch, need));
@@ -423,6 +423,8 @@ int jv_op_rowgemm(const float* A, int64_t rows, int M, int K, const float* W, in
   unsigned short* planes = static_cast<unsigned short*>(scratch);
   float* cs = reinterpret_cast<float*>(static_cast<char*>(scratch) + ((n * 4 + 63) & ~(size_t)63));
   JV_TRY(jv::split2h_planes(W, N, K, cs + N, planes, cs, st));
+  unsigned short* wf = reinterpret_cast<unsigned short*>(static_cast<char*>(scratch) + ((n * 4 + (size_t)N * 12 + 511) & ~(size_t)255));
+  if (!(K & 63)) JV_TRY(jv::pack_wfrag(planes, (long)n, K, N, K, wf, (long)n, st));
   static unsigned short* ap = nullptr;
   static size_t acap = 0;
   const size_t an = (size_t)rows * K;
@@ -436,6 +438,7 @@ int jv_op_rowgemm(const float* A, int64_t rows, int M, int K, const float* W, in
   a.A2 = ap; a.a2_plane = (long)an; a.a_rows = rows; a.lda2 = K;
   a.M = M; a.K = K; a.N = N;
   a.W2 = planes; a.w2_plane = (long)n; a.ldw = K; a.colscale = cs; a.a_scale = sc; a.bias = bias;
+  if (!(K & 63)) { a.Wf = wf; a.wf_plane = (long)n; }
   a.out = out; a.ldo = N; a.res = res; a.ldr = N;
   a.out2 = out2; a.out2_plane = (long)M * (epi == jv::RG_RES_LN ? 256 : N); a.ldo2 = epi == jv::RG_RES_LN ? 256 : N;
   a.out2_scale = out2_scale;

@@ -338,6 +338,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.A2 = reinterpret_cast<const unsigned short*>(planes); a.a2_plane = R * K; a.a_rows = g.a_rows; a.lda2 = K;
     a.M = (int)g.M; a.K = K; a.N = m.N;
     a.W2 = m.w2; a.w2_plane = (long)m.n_rows * m.ldw; a.ldw = m.ldw; a.colscale = m.colscale; a.a_scale = m.a_scale;
+    a.Wf = m.wf; a.wf_plane = (long)m.N * m.Cin;
     a.bias = m.bias; a.ln_eps = 1e-5f; a.out2_scale = 1.f;
     a.alg_rows = (long)g.B2 * g.T;
     return a;
@@ -380,8 +381,9 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
       a.out2 = reinterpret_cast<unsigned short*>(w.ff); a.out2_plane = R * 1024; a.ldo2 = 1024; a.out2_scale = b.ff2.a_scale;
       JV_TRY(rowgemm(a, RG_GELU_PL, st));
     } else {
-      // K = 256, N = 1024 with a GELU epilogue is where the tile kernel wins (traced 56 against 62 us): its 2-3 workgroups per
-      // CU run one's epilogue under another's main loop, which a one-workgroup-per-CU kernel cannot.  Same planes in and out.
+      // JV_TILE_FF1: the tile kernel, which beat the first row-owning kernel here (both operands through LDS: 62 us against
+      // 56); with the weights loaded straight into registers the row-owning kernel takes 56 alone and the whole pass 188 ms
+      // against 199 (same box, back to back).  Same planes in and out.
       ConvGemmArgs t = base_args(g, w.ln, 256, b.ff1, w.ff, 1024);
       t.act = ACT_GELU;
       h3(t, b.ff1);

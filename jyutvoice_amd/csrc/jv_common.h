@@ -217,6 +217,9 @@ struct SplitKReduceArgs {
   const float *ln2_g, *ln2_b; float* out2;              // optional: LayerNorm_256(out row) -> out2 [rows, 256]
 };
 int splitk_reduce_rows(const SplitKReduceArgs& a, hipStream_t st);
+// fp16 planes [2][N][ldw] (row n = output column n, K-contiguous) -> fragment order [2][N/16][K/32][64 lanes][8 halves]: lane
+// l of a v_mfma_f32_16x16x32_f16 B operand holds row 16 nb + (l & 15), k = 32 ks + 8 (l >> 4) ... + 8 (rowgemm.hip)
+int pack_wfrag(const unsigned short* w2, long w2_plane, int ldw, int N, int K, unsigned short* wf, long wf_plane, hipStream_t st);
 int layernorm256_planes(const float* x, unsigned short* out2, long plane, float scale, const float* g, const float* b, float eps,
                         long rows, hipStream_t st);
 

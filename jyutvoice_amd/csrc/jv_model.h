@@ -50,6 +50,7 @@ struct GemmW {
   const float* bias = nullptr;
   // fp16x3 path, attached only where a load-time bound on the layer's input exists (registry.hip `half3`):
   const unsigned short* w2 = nullptr;   // two fp16 planes of w[n][:] * 2^e_n
+  const unsigned short* wf = nullptr;   // the same two planes in MFMA-fragment order (rowgemm_kernel.h, `Wf`), plane stride N * Cin
   const float* colscale = nullptr;      // 2^-e_n
   float a_scale = 0.f;                  // power of two with bound(|input|) * a_scale < 65504; 0 = no bound, use bf16x6
 };
@@ -129,7 +130,7 @@ struct Context {
   bool noise_loaded = false;
   bool dma_a = false;            // JV_DMA_A=1: fp16x3 linears take their A operand pre-split from the producer (measured slower
                                  // in the pipeline than the in-kernel split; kept as a tested alternative)
-  bool rg_ff1 = false;           // JV_RG_FF1=1: ff.net.0 on the row-owning GEMM too (default: tile kernel, measured faster)
+  bool rg_ff1 = true;            // ff.net.0 on the row-owning GEMM too; JV_TILE_FF1=1: on the tile kernel (the round-2 first build, for A/B runs)
   bool no_attn_planes = false;   // JV_NO_ATTN_PLANES=1: attention splits K / V itself (attention.hip) instead of taking planes
   bool no_splitk = false;        // JV_NO_SPLITK=1: no split-K at short M (A/B aid)
   bool no_rowgemm = false;       // JV_NO_ROWGEMM=1: keep the transformer linears on the tile kernels at every batch size (A/B aid)

@@ -428,6 +428,18 @@ struct Packer {
     g.colscale = cs;
     return stats + g.n_rows;
   }
+  // ... and a second copy of the planes in fragment order for the row-owning GEMM (rowgemm_kernel.h, W-direct)
+  void wfrag(GemmW& g) {
+    if (!g.w2 || rc != JV_OK || g.ntaps != 1 || (g.N & 255) || (g.Cin & 63) || g.ldw != g.Cin) return;
+    const long n = (long)g.N * g.Cin;
+    float* d = alloc((size_t)n + 8);
+    if (!d) return;
+    if (pack_wfrag(g.w2, (long)g.n_rows * g.ldw, g.ldw, g.N, g.Cin, reinterpret_cast<unsigned short*>(d), n, st) != JV_OK) {
+      rc = JV_ERR_HIP;
+      return;
+    }
+    g.wf = reinterpret_cast<const unsigned short*>(d);
+  }
   // conv weight [cout][cin][k] (device, plain) -> GemmW with cin padded to cinp
   GemmW conv(const float* w, int cout, int cin, int k, int cinp, const float* bias) {
     GemmW g;
@@ -601,6 +613,7 @@ int finalize_model(Context& c, int model, hipStream_t st) {
         (void)pk.half3(w.out);
         const float* l1_ff1v = pk.half3(w.ff1);
         (void)pk.half3(w.ff2);
+        pk.wfrag(w.qkv); pk.wfrag(w.out); pk.wfrag(w.ff1); pk.wfrag(w.ff2);
         const float l1_q = pk.host_maxabs(l1_qkv, EST_INNER), l1_k = pk.host_maxabs(l1_qkv ? l1_qkv + EST_INNER : nullptr, EST_INNER);
         const float l1_v = pk.host_maxabs(l1_qkv ? l1_qkv + 2 * EST_INNER : nullptr, EST_INNER);
         const float l1_ff1 = pk.host_maxabs(l1_ff1v, EST_FF);

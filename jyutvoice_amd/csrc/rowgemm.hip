@@ -5,6 +5,31 @@ namespace jv {
 
 namespace {
 
+__global__ void pack_wfrag_kernel(const unsigned short* __restrict__ w2, long w2_plane, int ldw, int NB, int KS,
+                                  unsigned short* __restrict__ wf, long wf_plane) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= 2L * NB * KS * 64) return;
+  const int lane = (int)(t & 63);
+  const long f = t >> 6;
+  const int ks = (int)(f % KS), nb = (int)((f / KS) % NB), pl = (int)(f / ((long)KS * NB));
+  const uint4 v = *reinterpret_cast<const uint4*>(w2 + pl * w2_plane + (long)(nb * 16 + (lane & 15)) * ldw + ks * 32 + (lane >> 4) * 8);
+  *reinterpret_cast<uint4*>(wf + pl * wf_plane + (((long)nb * KS + ks) * 64 + lane) * 8) = v;
+}
+
+template <int RT, int EPI>
+int rg_launch_wd(const RowGemmArgs& a, hipStream_t st) {
+  static bool raised[64] = {};
+  int dev = 0;
+  JV_HIP(hipGetDevice(&dev));
+  if (!raised[dev & 63]) {
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_wd_kernel<RT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               rgw_lds_bytes<RT>()));
+    raised[dev & 63] = true;
+  }
+  hipLaunchKernelGGL((rowgemm_wd_kernel<RT, EPI>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rgw_lds_bytes<RT>(), st, a);
+  return JV_OK;
+}
+
 template <int RT, int EPI>
 int rg_launch2(const RowGemmArgs& a, hipStream_t st) {
   static bool raised[64] = {};      // per device: the attribute belongs to the kernel's image on the current device
@@ -17,7 +42,8 @@ int rg_launch2(const RowGemmArgs& a, hipStream_t st) {
   }
   const bool prof = prof_on();
   if (prof) prof_begin(st);
-  hipLaunchKernelGGL((rowgemm_kernel<RT, EPI>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rg_lds_bytes<RT>(), st, a);
+  if (a.Wf && !(a.K & 63) && !dyn_env("JV_RG_WLDS")) JV_TRY((rg_launch_wd<RT, EPI>(a, st)));
+  else hipLaunchKernelGGL((rowgemm_kernel<RT, EPI>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rg_lds_bytes<RT>(), st, a);
   if (prof) {
     static const std::string name = std::string("rowgemm_h3<") + std::to_string(16 * RT) + "x256" +
                                     (EPI == RG_GELU_PL ? ",gelu" : EPI == RG_RES ? ",res" : EPI == RG_RES_LN ? ",res,ln" : EPI == RG_QKV ? ",qkv" : "") + ">";
@@ -43,6 +69,15 @@ int rg_launch1(const RowGemmArgs& a, int epi, hipStream_t st) {
 }
 
 }  // namespace
+
+int pack_wfrag(const unsigned short* w2, long w2_plane, int ldw, int N, int K, unsigned short* wf, long wf_plane, hipStream_t st) {
+  if (!w2 || !wf || (N & 15) || (K & 31) || (ldw & 7)) return fail(JV_ERR_ARG, "pack_wfrag: N % 16 == 0, K % 32 == 0, ldw % 8 == 0 required");
+  const long total = 2L * (N >> 4) * (K >> 5) * 64;
+  hipLaunchKernelGGL(pack_wfrag_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, w2, w2_plane, ldw, N >> 4, K >> 5, wf,
+                     wf_plane);
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
 
 // tile height (in 16-row units) for M rows: the fewest rounds of workgroups over the 256 CUs times the rows each round
 // costs; ties go to the taller tile (each weight byte is then used for more rows).  0: use the tile kernels -- too few rows

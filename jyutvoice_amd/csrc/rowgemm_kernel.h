@@ -53,6 +53,8 @@ struct RowGemmArgs {
   const unsigned short* W2;
   long w2_plane;
   int ldw;
+  const unsigned short* Wf;      // the same planes in fragment order (rowgemm_wd_kernel), plane stride wf_plane halves; null: W2 through LDS
+  long wf_plane;
   const float* colscale;
   float a_scale;      // the power of two A was scaled with (a load-time bound, GemmW::a_scale)
   const float* bias;  // [N] or null
@@ -72,7 +74,8 @@ struct RowGemmArgs {
   const int* row_slot;
   const unsigned char* row_mask;
   long alg_rows;      // profiler: real frames
-  int ablate;         // tuning aid (JV_RG_ABLATE, tuning builds): 1 no DMA in the loop, 2 no LDS reads + MFMAs, 4 no barrier/wait
+  int ablate;         // tuning aid (JV_RG_ABLATE, tuning builds): 1 no loads in the loop, 2 no MFMAs, 4 no barrier/wait (LDS kernel),
+                      // W-direct kernel also: 8 no LDS fragment reads, 16 no W loads, 32 no A DMA, 64 no row pass
 };
 
 constexpr int RG_SLD = 260;                      // slab row stride in floats (256 + 4: conflict-free b32 writes, aligned b128 reads)
@@ -414,6 +417,388 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const RowGemmArgs p) {
     }
   }
   asm volatile("" ::"v"(warm));      // the warm-up load is waited for here, not before
+}
+
+// ---- the same GEMM with the weight fragments loaded straight into registers ("W-direct") --------------------------------
+// In the kernel above both operands go through LDS.  Per 32-deep step and CU that is 42 KB of DMA writes plus 112 KB of
+// fragment reads (every wave reads all 80 rows of A, 10 KB, and its own 32 columns of W, 4 KB) = ~1200 LDS cycles at
+// 128 B/clk against 960 matrix-pipe cycles (30 MFMAs x 16 clk x 2 waves per SIMD): LDS-bound, and the ablations agree (DMA
+// alone and MFMA alone each take 60 % of the loop they make together).  But W is not shared inside the workgroup -- each
+// wave owns 32 columns -- so staging it in LDS buys nothing except asynchrony.  Here the weights are stored a second time in
+// FRAGMENT ORDER (RowGemmArgs::Wf: for each plane, 16-column block and 32-deep k-step, 1 KB holding lane l's 8 halves at
+// l * 16 B; registry.hip packs it at load time), each wave loads its four fragments of a step with four fully coalesced
+// global_load_dwordx4 two steps ahead into a register double buffer, and LDS carries only A: 10 KB written and 80 KB read
+// per step, ~700 cycles, under the matrix pipe's 960.  The ring is A-only (3 x 10 KB), which leaves room for a slab of the
+// whole tile (83 KB) beside it: every chunk's epilogue is one pass, and the ring keeps streaming underneath it.
+constexpr int RGW_NST = 3;
+template <int RT> constexpr int rgw_stage_bytes() { return 2 * 16 * RT * 64; }
+template <int RT> constexpr int rgw_lds_bytes() { return RGW_NST * rgw_stage_bytes<RT>() + 16 * RT * RG_SLD * 4; }
+
+template <int RT, int EPI>
+__global__ __launch_bounds__(512, 2) void rowgemm_wd_kernel(const RowGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rg_lds[];
+  constexpr int R = 16 * RT;
+  constexpr int STAGE = rgw_stage_bytes<RT>();
+  constexpr int A_PLANE = R * 64;
+  constexpr int NPIECE = 2 * RT;                 // 1 KiB DMA pieces per stage: RT per A plane
+  constexpr int PPW = (NPIECE + 7) / 8;          // issued per wave and step, at most
+  constexpr int NWL = 4;                         // weight loads per wave and step: 2 column blocks x 2 planes
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * R;
+  // (the residual epilogues own whole 256-wide rows: one chunk, known at compile time, so that nothing of the main loop is
+  // live in their register-hungry row pass)
+  const int KS = p.K >> 5, NC = (EPI == RG_RES || EPI == RG_RES_LN) ? 1 : p.N >> 8;
+  const int total = KS * NC;
+  float* const big = reinterpret_cast<float*>(rg_lds + RGW_NST * STAGE);
+
+  // warm this XCD's L2 with the weights (see rowgemm_kernel above)
+  float warm = 0.f;
+  {
+    const long lpp = ((long)p.N * p.K * 2) >> 7;                   // 128-byte lines per plane
+    const int grp = blockIdx.x >> 3, ngrp = (gridDim.x + 7) >> 3;
+    const long per = (2 * lpp + ngrp - 1) / ngrp;
+    const long l = (long)grp * per + tid;
+    if (tid < per && l < 2 * lpp) {
+      const int pl = l >= lpp;
+      warm = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.Wf + (long)pl * p.wf_plane) + ((l - pl * lpp) << 7));
+    }
+  }
+
+  // ---- A: this wave's DMA pieces ----
+  const unsigned short* cur[PPW];
+  int dst[PPW];
+  {
+    const int prow = lane >> 2, pslot = (lane & 3) ^ rg_key(prow);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave + 8 * i;
+      const int pl = pc / RT, g = pc % RT;
+      long row = (long)m0 + g * 16 + prow;
+      row = row < p.a_rows ? row : p.a_rows - 1;
+      cur[i] = p.A2 + (long)(pl & 1) * p.a2_plane + row * p.lda2 + 8 * pslot;
+      dst[i] = (pl & 1) * A_PLANE + g * 1024;
+    }
+  }
+  const int my_pieces = (NPIECE - wave + 7) / 8 > 0 ? (NPIECE - wave + 7) / 8 : 0;      // wave-uniform
+  int ik = 0;
+  auto issue_piece = [&](auto itag, int stage) {
+    constexpr int i = decltype(itag)::value;
+    if (wave + 8 * i < NPIECE) {      // wave-uniform
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)cur[i],
+                                       (__attribute__((address_space(3))) void*)(rg_lds + stage * STAGE + dst[i]), 16, 0, 0);
+    }
+  };
+  auto advance = [&]() {      // A walks k within the row and starts over for every chunk
+    const bool wrap = ++ik == KS;
+    if (wrap) ik = 0;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) cur[i] += wrap ? 32 - p.K : 32;
+  };
+  // ---- W: fragment-ordered, [plane][N/16][KS][64 lanes][8 halves]; this wave's column blocks are c*16 + wave*2 + nt ----
+  // one wave-uniform 64-bit base that walks the (chunk, k-step) sequence, and four constant per-lane byte offsets (column
+  // block nt, plane pl): global_load_dwordx4 v, v_offset, s[base] -- no per-lane 64-bit address arithmetic in the loop
+  const char* wptr = reinterpret_cast<const char*>(p.Wf) + ((long)wave * 2 * KS) * 1024;
+  unsigned wvo[2][2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) wvo[nt][pl] = (unsigned)(lane * 16 + nt * KS * 1024 + pl * p.wf_plane * 2);
+  int wk = 0;
+  // The register double buffer is loaded and waited for by hand (inline asm): left to the compiler, the wait in front of
+  // the first MFMA of a step becomes s_waitcnt vmcnt(0) -- its bookkeeping gives up on loads carried around the loop --
+  // and the two steps of lookahead are gone.  The asm load is invisible to that bookkeeping, so (a) nothing but the MFMAs
+  // below may read bq, which the "+v" operands of wait_w order behind the counted wait, and (b) the register allocator
+  // must not copy bq while a load is in flight: tools/check_rowgemm_isa.py checks the built code object for both.
+  rg_u32x4 bq[2][2][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bq[i >> 2][(i >> 1) & 1][i & 1] = rg_u32x4{0u, 0u, 0u, 0u};
+  auto load_frag = [](rg_u32x4& dst, unsigned voff, const char* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory");
+  };
+  auto load_w = [&](auto par_tag, auto nttag) {
+    constexpr int par = decltype(par_tag)::value, nt = decltype(nttag)::value;
+    load_frag(bq[par][nt][0], wvo[nt][0], wptr);
+    load_frag(bq[par][nt][1], wvo[nt][1], wptr);
+  };
+  auto landed_w = [](rg_u32x4& b00, rg_u32x4& b01, rg_u32x4& b10, rg_u32x4& b11) {
+    asm volatile("" : "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11)::"memory");
+  };
+  int wc = 0;
+  auto advance_w = [&]() {      // + 1 KB per step, + 15 KS KB more at a chunk boundary, back to the start after the last chunk
+    const bool wrap = ++wk == KS;
+    if (wrap) {
+      wk = 0;
+      const bool end = ++wc == NC;
+      if (end) wc = 0;
+      wptr += end ? 1024L + 15L * KS * 1024 - 16L * KS * 1024 * NC : 1024L + 15L * KS * 1024;
+    } else {
+      wptr += 1024L;
+    }
+  };
+
+  const int fslot = (kq ^ rg_key(r16)) << 4;
+  const int a_off = r16 * 64 + fslot;
+
+  rg_f32x4 acc[RT][2];
+  // A fragments, double-buffered in registers by step parity: the reads of step s + 1 are issued in the middle of step s
+  rg_u32x4 af[2][RT][2];
+  auto read_a = [&](auto par_tag, int stage) {
+    constexpr int par = decltype(par_tag)::value;
+    const unsigned char* const st = rg_lds + stage * STAGE;
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) af[par][mt][pl] = *reinterpret_cast<const rg_u32x4*>(st + a_off + pl * A_PLANE + mt * 1024);
+  };
+  // prologue: A of steps 0, 1, 2 into the three stages, W of steps 0 and 1 into the two register buffers (K % 64 == 0: there
+  // are at least two steps); everything is waited for once, then step 0's fragments are read
+  issue_piece(std::integral_constant<int, 0>{}, 0);
+  if constexpr (PPW > 1) issue_piece(std::integral_constant<int, 1>{}, 0);
+  advance();
+  load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+  advance_w();
+  issue_piece(std::integral_constant<int, 0>{}, 1);
+  if constexpr (PPW > 1) issue_piece(std::integral_constant<int, 1>{}, 1);
+  advance();
+  load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+  load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+  advance_w();
+  issue_piece(std::integral_constant<int, 0>{}, 2);
+  if constexpr (PPW > 1) issue_piece(std::integral_constant<int, 1>{}, 2);
+  advance();
+  rg_wait_vmcnt<0>();
+  landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
+  landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
+  rg_barrier();
+  read_a(std::integral_constant<int, 0>{}, 0);
+
+  int s = 0, s3 = 0;      // step, step % 3
+  for (int c = 0; c < NC; ++c) {
+    const int n0 = c * 256 + 4 * lane;
+    rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.colscale + n0);
+    cs4 = cs4 * (1.0f / p.a_scale);
+    rg_f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) b4 = *reinterpret_cast<const rg_f32x4*>(p.bias + n0);
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // One 32-deep step, software-pipelined across the workgroup barrier; `par` = s & 1 picks the register buffers.
+    //   block 0: column block 0 x all row groups (fragments af[par], bq[par][0] -- both in registers since the middle of
+    //            step s - 1), then bq[par][0] is reloaded for step s + 2;
+    //   middle:  counted wait + barrier: A of step s + 1 has landed for every wave (and this wave's W0 of step s + 1 and W1
+    //            of step s), and every wave has finished reading stage s % 3 (read in the middle of step s - 1); step s + 1's
+    //            fragments are requested into af[par ^ 1] -- their LDS latency hides behind block 1 -- and step s + 3's A
+    //            pieces go into stage s % 3, one per MFMA group;
+    //   block 1: column block 1, then bq[par][1] is reloaded for step s + 2.
+    // With the barrier at the head of the step instead (first version), each step began with wait -> barrier -> LDS reads
+    // -> first MFMA in all eight waves at once and an idle matrix pipe: an ablated kernel with no loads, no MFMAs and no
+    // LDS reads still took 0.5 us per step, which added to the 0.35 us of MFMA work instead of hiding under it.
+    // The counted wait: program order of this wave's memory operations is
+    //   ... W0(s+1), A(s+2), W1(s+1) | W0(s+2), <wait of step s>, A(s+3), W1(s+2) | ...
+    // and what must have landed is A(s+1), W0(s+1), W1(s) -- the youngest of them W0(s+1), with A(s+2), W1(s+1), W0(s+2)
+    // behind it: at most my_pieces + 4 outstanding (vmcnt counts loads and LDS-DMA alike and retires them in order).
+    // Every step issues its loads unconditionally -- past the end of the launch they wrap around to operands that exist and
+    // land where nothing reads them -- so that the loop body has no tail cases: one counted wait, no branches but the
+    // my_pieces one.  (Peeling a branch-free steady state off a general tail instead made the register allocator give the
+    // two copies different registers for bq and move the buffer between them with a load in flight.)
+    auto step = [&](auto par_tag) {
+      constexpr int par = decltype(par_tag)::value;
+      const bool more_a = !JV_ABLATE(p, 1) && !JV_ABLATE(p, 32), more_w = !JV_ABLATE(p, 1) && !JV_ABLATE(p, 16);
+      auto group = [&](auto mtag, auto nttag) {
+        constexpr int mt = decltype(mtag)::value, nt = decltype(nttag)::value;
+        if (!JV_ABLATE(p, 2)) {
+          rg_f32x4 t = acc[mt][nt];
+          auto mm = [&](const rg_u32x4& x, const rg_u32x4& y) {
+            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rg_f16x8, x), __builtin_bit_cast(rg_f16x8, y), t, 0, 0, 0);
+          };
+          mm(af[par][mt][1], bq[par][nt][0]);      // smallest terms first, as the tile kernels do
+          mm(af[par][mt][0], bq[par][nt][1]);
+          mm(af[par][mt][0], bq[par][nt][0]);
+          acc[mt][nt] = t;
+        }
+        if constexpr (nt == 1 && mt < PPW) {
+          if (more_a) issue_piece(std::integral_constant<int, (mt < PPW ? mt : 0)>{}, s3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto block = [&](auto nttag) {
+        group(std::integral_constant<int, 0>{}, nttag);
+        if constexpr (RT > 1) group(std::integral_constant<int, 1>{}, nttag);
+        if constexpr (RT > 2) group(std::integral_constant<int, 2>{}, nttag);
+        if constexpr (RT > 3) group(std::integral_constant<int, 3>{}, nttag);
+        if constexpr (RT > 4) group(std::integral_constant<int, 4>{}, nttag);
+        if (more_w) load_w(par_tag, nttag);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      block(std::integral_constant<int, 0>{});
+      if (my_pieces == PPW) rg_wait_vmcnt<NWL + PPW>();
+      else rg_wait_vmcnt<NWL + PPW - 1>();
+      landed_w(bq[par][1][0], bq[par][1][1], bq[par ^ 1][0][0], bq[par ^ 1][0][1]);
+      if (!JV_ABLATE(p, 4)) rg_barrier();
+      const int s3n = s3 == 2 ? 0 : s3 + 1;      // (s + 1) % 3
+      if (!JV_ABLATE(p, 8)) read_a(std::integral_constant<int, par ^ 1>{}, s3n);
+      __builtin_amdgcn_sched_barrier(0);
+      block(std::integral_constant<int, 1>{});
+      if (more_a) advance();
+      if (more_w) advance_w();
+      ++s;
+      s3 = s3n;
+    };
+    for (int ks = 0; ks < KS; ks += 2) {
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+    }
+
+    // residual epilogues: the rows' residual values, tracking slots and masks are requested BEFORE the accumulators go
+    // through the slab, so their latency (the residual was written by the previous launch: L2 or further) hides behind the
+    // slab pass and its barrier instead of stalling each half of the row pass
+    constexpr int NRW = 2 * RT;      // rows per wave
+    constexpr bool RESID = EPI == RG_RES || EPI == RG_RES_LN;
+    rg_f32x4 rpre[RESID ? NRW : 1];
+    unsigned seenpre[RESID ? NRW : 1];
+    bool trkpre[RESID ? NRW : 1];
+    if constexpr (RESID) {
+#pragma unroll
+      for (int j = 0; j < NRW; ++j) {
+        const long mr = (long)m0 + wave * NRW + j;
+        const bool okj = mr < p.M;
+        rpre[j] = okj ? *reinterpret_cast<const rg_f32x4*>(p.res + mr * p.ldr + 4 * lane) : rg_f32x4{0.f, 0.f, 0.f, 0.f};
+        trkpre[j] = false;
+        seenpre[j] = 0xffffffffu;
+        if (p.amax_out && okj) {
+          trkpre[j] = !p.row_mask || p.row_mask[mr] != 0;
+          // (a plain, cacheable load: the slot only grows, so a stale value is a valid lower bound)
+          seenpre[j] = *reinterpret_cast<const unsigned*>(p.amax_out + (p.row_slot ? p.row_slot[mr] : 0));
+        }
+      }
+    }
+    auto rows_body = [&](auto rpw_tag, const float* sl, const int trow0, const int srow0, auto pre_tag) {
+      constexpr int RPW = decltype(rpw_tag)::value;
+      constexpr int PRE = decltype(pre_tag)::value;      // first index into rpre / seenpre / trkpre
+      rg_f32x4 v[RPW];
+      long mrow[RPW];
+      bool ok[RPW];
+#pragma unroll
+      for (int j = 0; j < RPW; ++j) {
+        const int trow = trow0 + j;
+        mrow[j] = (long)m0 + trow;
+        ok[j] = trow < R && mrow[j] < p.M;
+        v[j] = *reinterpret_cast<const rg_f32x4*>(sl + (srow0 + j) * RG_SLD + 4 * lane) * cs4 + b4;
+      }
+      if constexpr (EPI == RG_PLAIN) {
+#pragma unroll
+        for (int j = 0; j < RPW; ++j)
+          if (ok[j]) *reinterpret_cast<rg_f32x4*>(p.out + mrow[j] * p.ldo + n0) = v[j];
+      } else if constexpr (EPI == RG_QKV) {
+        if (c < 2) {      // q (chunk-uniform branch)
+#pragma unroll
+          for (int j = 0; j < RPW; ++j)
+            if (ok[j]) *reinterpret_cast<rg_f32x4*>(p.out + mrow[j] * p.ldo + n0) = v[j];
+        } else {
+          const float sc = c < 4 ? p.out2_scale : p.out2_scale2;
+#pragma unroll
+          for (int j = 0; j < RPW; ++j) {
+            if (!ok[j]) continue;
+            const Split2 s0 = split2h_pair(v[j][0] * sc, v[j][1] * sc);
+            const Split2 s1 = split2h_pair(v[j][2] * sc, v[j][3] * sc);
+            unsigned short* o2 = p.out2 + mrow[j] * p.ldo2 + (n0 - 512);
+            *reinterpret_cast<rg_u32x2*>(o2) = rg_u32x2{s0.h, s1.h};
+            *reinterpret_cast<rg_u32x2*>(o2 + p.out2_plane) = rg_u32x2{s0.l, s1.l};
+          }
+        }
+      } else if constexpr (EPI == RG_GELU_PL) {
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+          if (!ok[j]) continue;
+          rg_f32x4 t = v[j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = gelu_erf(t[e]);
+          const Split2 s0 = split2h_pair(t[0] * p.out2_scale, t[1] * p.out2_scale);
+          const Split2 s1 = split2h_pair(t[2] * p.out2_scale, t[3] * p.out2_scale);
+          unsigned short* o2 = p.out2 + mrow[j] * p.ldo2 + n0;
+          *reinterpret_cast<rg_u32x2*>(o2) = rg_u32x2{s0.h, s1.h};
+          *reinterpret_cast<rg_u32x2*>(o2 + p.out2_plane) = rg_u32x2{s0.l, s1.l};
+        }
+      } else {
+        // + residual -> fp32 rows (+ tracking) (-> LayerNorm -> planes)
+        rg_f32x4 r[RPW];
+        unsigned seen[RPW];
+        bool tracked[RPW];
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+          r[j] = rpre[RESID ? PRE + j : 0];
+          tracked[j] = trkpre[RESID ? PRE + j : 0];
+          seen[j] = seenpre[RESID ? PRE + j : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+          v[j] += r[j];
+          if (ok[j]) *reinterpret_cast<rg_f32x4*>(p.out + mrow[j] * p.ldo + 4 * lane) = v[j];
+        }
+        if (p.amax_out) {
+#pragma unroll
+          for (int j = 0; j < RPW; ++j) {
+            unsigned u = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u = max(u, __float_as_uint(v[j][e]) & 0x7fffffffu);
+            // wave-uniform branch (a wave holds whole rows): nothing to do once the slot holds a larger value
+            if (tracked[j] && __builtin_amdgcn_ballot_w64(u > seen[j]) != 0) {
+#pragma unroll
+              for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o));
+              if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(p.amax_out + (p.row_slot ? p.row_slot[mrow[j]] : 0)), u);
+            }
+          }
+        }
+        if constexpr (EPI == RG_RES_LN) {
+          // LayerNorm over the row's 256 channels (two-pass, as rowops.hip's layernorm256_kernel), written as the next
+          // GEMM's pre-split operand
+          const rg_f32x4 gg = *reinterpret_cast<const rg_f32x4*>(p.ln_g + 4 * lane);
+          const rg_f32x4 bb = *reinterpret_cast<const rg_f32x4*>(p.ln_b + 4 * lane);
+          float sum[RPW], sq[RPW];
+#pragma unroll
+          for (int j = 0; j < RPW; ++j) sum[j] = wave_sum((v[j][0] + v[j][1]) + (v[j][2] + v[j][3]));
+#pragma unroll
+          for (int j = 0; j < RPW; ++j) {
+            const rg_f32x4 d = v[j] - sum[j] * (1.f / 256.f);
+            sq[j] = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+          }
+#pragma unroll
+          for (int j = 0; j < RPW; ++j) {
+            if (!ok[j]) continue;
+            const float mean = sum[j] * (1.f / 256.f);
+            const float rstd = 1.0f / sqrtf(sq[j] * (1.f / 256.f) + p.ln_eps);
+            const rg_f32x4 y = (v[j] - mean) * rstd * gg + bb;
+            const Split2 s0 = split2h_pair(y[0] * p.out2_scale, y[1] * p.out2_scale);
+            const Split2 s1 = split2h_pair(y[2] * p.out2_scale, y[3] * p.out2_scale);
+            unsigned short* o2 = p.out2 + mrow[j] * p.ldo2 + 4 * lane;
+            *reinterpret_cast<rg_u32x2*>(o2) = rg_u32x2{s0.h, s1.h};
+            *reinterpret_cast<rg_u32x2*>(o2 + p.out2_plane) = rg_u32x2{s0.l, s1.l};
+          }
+        }
+      }
+    };
+
+    // the whole tile through its own slab, one pass: every wave takes its 2 RT rows RT at a time.  No barrier after the
+    // row pass: the slab is next written a whole main loop (>= 2 barriers) later.
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) big[(mt * 16 + kq * 4 + e) * RG_SLD + wave * 32 + nt * 16 + r16] = acc[mt][nt][e];
+    rg_lds_barrier();
+    if (!JV_ABLATE(p, 64)) {
+      rows_body(std::integral_constant<int, RT>{}, big, wave * 2 * RT, wave * 2 * RT, std::integral_constant<int, 0>{});
+      rows_body(std::integral_constant<int, RT>{}, big, wave * 2 * RT + RT, wave * 2 * RT + RT, std::integral_constant<int, RT>{});
+    }
+  }
+  rg_wait_vmcnt<0>();      // the wrapped-around loads of the last steps: no LDS-DMA may outlive the workgroup
+  asm volatile("" ::"v"(warm));
 }
 
 }  // namespace jv

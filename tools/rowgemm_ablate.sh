@@ -13,7 +13,7 @@ for ab in ${1:-0 1 2 4}; do
 import csv, glob, os
 names = ["qkv K256 N1536", "ff1 K256 N1024", "ff2 K1024 N256", "out K512 N256", "res K256 N256"]
 for f in glob.glob(os.path.join("$OUT", "a$ab", "**", "*kernel_trace.csv"), recursive=True):
-    rows = [r for r in csv.DictReader(open(f)) if "rowgemm_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "rowgemm_" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     per = len(rows) // len(names)
     out = []

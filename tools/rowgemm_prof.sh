@@ -16,7 +16,7 @@ import csv, glob, os
 names = ["qkv K256 N1536", "ff1 K256 N1024", "ff2 K1024 N256", "out K512 N256", "res K256 N256"]
 for d in ("plain", "gelu", "res", "res_ln", "tile"):
     for f in glob.glob(os.path.join("$OUT", d, "**", "*kernel_trace.csv"), recursive=True):
-        rows = [r for r in csv.DictReader(open(f)) if "rowgemm_kernel" in r["Kernel_Name"] or "conv_gemm_x6_kernel" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if "rowgemm_" in r["Kernel_Name"] or "conv_gemm_x6_kernel" in r["Kernel_Name"]]
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
         sh = names if d in ("plain", "gelu", "tile") else names[2:]
         per = len(rows) // len(sh) if sh else 0
