@@ -497,14 +497,17 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wd_kernel(const RowGemmArgs p)
     for (int i = 0; i < PPW; ++i) cur[i] += wrap ? 32 - p.K : 32;
   };
   // ---- W: fragment-ordered, [plane][N/16][KS][64 lanes][8 halves]; this wave's column blocks are c*16 + wave*2 + nt ----
-  // one wave-uniform 64-bit base that walks the (chunk, k-step) sequence, and four constant per-lane byte offsets (column
-  // block nt, plane pl): global_load_dwordx4 v, v_offset, s[base] -- no per-lane 64-bit address arithmetic in the loop
-  const char* wptr = reinterpret_cast<const char*>(p.Wf) + ((long)wave * 2 * KS) * 1024;
-  unsigned wvo[2][2];
+  // per-lane pointers of the four fragments (column block nt, plane pl) at (chunk 0, step 0); `woff` walks the (chunk,
+  // k-step) sequence in halves.  (A scalar base with 32-bit lane offsets -- global_load_dwordx4 v, v_off, s[base] -- would
+  // save the 64-bit adds, but from inline asm it faulted: the base reached the asm through v_readfirstlane, and a VMEM
+  // instruction reading an SGPR that a VALU instruction has just written needs wait states the compiler's hazard
+  // recognizer does not insert around inline asm.)
+  const unsigned short* wbase[2][2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) wvo[nt][pl] = (unsigned)(lane * 16 + nt * KS * 1024 + pl * p.wf_plane * 2);
+    for (int pl = 0; pl < 2; ++pl) wbase[nt][pl] = p.Wf + (long)pl * p.wf_plane + ((long)(wave * 2 + nt) * KS) * 512 + lane * 8;
+  long woff = 0;
   int wk = 0;
   // The register double buffer is loaded and waited for by hand (inline asm): left to the compiler, the wait in front of
   // the first MFMA of a step becomes s_waitcnt vmcnt(0) -- its bookkeeping gives up on loads carried around the loop --
@@ -514,27 +517,27 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wd_kernel(const RowGemmArgs p)
   rg_u32x4 bq[2][2][2];
 #pragma unroll
   for (int i = 0; i < 8; ++i) bq[i >> 2][(i >> 1) & 1][i & 1] = rg_u32x4{0u, 0u, 0u, 0u};
-  auto load_frag = [](rg_u32x4& dst, unsigned voff, const char* sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory");
+  auto load_frag = [](rg_u32x4& dst, const unsigned short* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(ptr) : "memory");
   };
   auto load_w = [&](auto par_tag, auto nttag) {
     constexpr int par = decltype(par_tag)::value, nt = decltype(nttag)::value;
-    load_frag(bq[par][nt][0], wvo[nt][0], wptr);
-    load_frag(bq[par][nt][1], wvo[nt][1], wptr);
+    load_frag(bq[par][nt][0], wbase[nt][0] + woff);
+    load_frag(bq[par][nt][1], wbase[nt][1] + woff);
   };
   auto landed_w = [](rg_u32x4& b00, rg_u32x4& b01, rg_u32x4& b10, rg_u32x4& b11) {
     asm volatile("" : "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11)::"memory");
   };
   int wc = 0;
-  auto advance_w = [&]() {      // + 1 KB per step, + 15 KS KB more at a chunk boundary, back to the start after the last chunk
+  auto advance_w = [&]() {      // + 1 KB (512 halves) per step, + 15 KS KB more at a chunk boundary, back to the start after the last chunk
     const bool wrap = ++wk == KS;
     if (wrap) {
       wk = 0;
       const bool end = ++wc == NC;
       if (end) wc = 0;
-      wptr += end ? 1024L + 15L * KS * 1024 - 16L * KS * 1024 * NC : 1024L + 15L * KS * 1024;
+      woff += end ? 512L + 15L * KS * 512 - 16L * KS * 512 * NC : 512L + 15L * KS * 512;
     } else {
-      wptr += 1024L;
+      woff += 512L;
     }
   };
 
@@ -576,6 +579,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wd_kernel(const RowGemmArgs p)
   read_a(std::integral_constant<int, 0>{}, 0);
 
   int s = 0, s3 = 0;      // step, step % 3
+  bool waited = false;
   for (int c = 0; c < NC; ++c) {
     const int n0 = c * 256 + 4 * lane;
     rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.colscale + n0);
@@ -636,8 +640,13 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wd_kernel(const RowGemmArgs p)
         __builtin_amdgcn_sched_barrier(0);
       };
       block(std::integral_constant<int, 0>{});
-      if (my_pieces == PPW) rg_wait_vmcnt<NWL + PPW>();
-      else rg_wait_vmcnt<NWL + PPW - 1>();
+      // (the first step after a chunk's epilogue: what it needs was waited for BEFORE the epilogue's stores were issued,
+      // below -- counting here would wait for those stores, vmcnt being in order)
+      if (!waited) {
+        if (my_pieces == PPW) rg_wait_vmcnt<NWL + PPW>();
+        else rg_wait_vmcnt<NWL + PPW - 1>();
+      }
+      waited = false;
       landed_w(bq[par][1][0], bq[par][1][1], bq[par ^ 1][0][0], bq[par ^ 1][0][1]);
       if (!JV_ABLATE(p, 4)) rg_barrier();
       const int s3n = s3 == 2 ? 0 : s3 + 1;      // (s + 1) % 3
@@ -653,6 +662,13 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wd_kernel(const RowGemmArgs p)
       step(std::integral_constant<int, 0>{});
       step(std::integral_constant<int, 1>{});
     }
+    if (c + 1 < NC) {
+      // the next step's middle needs A(s + 1), W0(s + 1), W1(s); behind the youngest of them, W0(s + 1), only A(s + 2) and
+      // W1(s + 1) have been issued so far
+      if (my_pieces == PPW) rg_wait_vmcnt<2 + PPW>();
+      else rg_wait_vmcnt<2 + PPW - 1>();
+      waited = true;
+    }
 
     // residual epilogues: the rows' residual values, tracking slots and masks are requested BEFORE the accumulators go
     // through the slab, so their latency (the residual was written by the previous launch: L2 or further) hides behind the
@@ -665,16 +681,29 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wd_kernel(const RowGemmArgs p)
     if constexpr (RESID) {
 #pragma unroll
       for (int j = 0; j < NRW; ++j) {
-        const long mr = (long)m0 + wave * NRW + j;
-        const bool okj = mr < p.M;
-        rpre[j] = okj ? *reinterpret_cast<const rg_f32x4*>(p.res + mr * p.ldr + 4 * lane) : rg_f32x4{0.f, 0.f, 0.f, 0.f};
+        // rows past M are clamped to the last one (their results are never stored or tracked): unconditional loads, issued
+        // back to back -- behind a per-row branch the compiler waited for each before requesting the next
+        const long mr0 = (long)m0 + wave * NRW + j;
+        const long mr = mr0 < p.M ? mr0 : (long)p.M - 1;
+        rpre[j] = *reinterpret_cast<const rg_f32x4*>(p.res + mr * p.ldr + 4 * lane);
+      }
+#pragma unroll
+      for (int j = 0; j < NRW; ++j) {
         trkpre[j] = false;
         seenpre[j] = 0xffffffffu;
-        if (p.amax_out && okj) {
-          trkpre[j] = !p.row_mask || p.row_mask[mr] != 0;
-          // (a plain, cacheable load: the slot only grows, so a stale value is a valid lower bound)
-          seenpre[j] = *reinterpret_cast<const unsigned*>(p.amax_out + (p.row_slot ? p.row_slot[mr] : 0));
+      }
+      if (p.amax_out) {      // masks and slots of all rows first, then the slots' current maxima: two latencies, not 2 NRW
+        int slot[NRW];
+#pragma unroll
+        for (int j = 0; j < NRW; ++j) {
+          const long mr0 = (long)m0 + wave * NRW + j;
+          const long mr = mr0 < p.M ? mr0 : (long)p.M - 1;
+          trkpre[j] = mr0 < p.M && (!p.row_mask || p.row_mask[mr] != 0);
+          slot[j] = p.row_slot ? p.row_slot[mr] : 0;
         }
+        // (plain, cacheable loads: a slot only grows, so a stale value is a valid lower bound)
+#pragma unroll
+        for (int j = 0; j < NRW; ++j) seenpre[j] = *reinterpret_cast<const unsigned*>(p.amax_out + slot[j]);
       }
     }
     auto rows_body = [&](auto rpw_tag, const float* sl, const int trow0, const int srow0, auto pre_tag) {
@@ -797,7 +826,13 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wd_kernel(const RowGemmArgs p)
       rows_body(std::integral_constant<int, RT>{}, big, wave * 2 * RT + RT, wave * 2 * RT + RT, std::integral_constant<int, RT>{});
     }
   }
-  rg_wait_vmcnt<0>();      // the wrapped-around loads of the last steps: no LDS-DMA may outlive the workgroup
+  // The wrapped-around loads of the last two steps land after the loop: no LDS-DMA may outlive the workgroup, and bq must
+  // stay RESERVED until they have landed -- the compiler does not know about the asm loads in flight, and once it saw bq
+  // dead after the last step (the single-chunk residual epilogues) it kept a pointer there, which such a load then
+  // overwrote (a memory fault).  The empty asm below makes every bq register live up to this point.
+  rg_wait_vmcnt<0>();
+  landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
+  landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
   asm volatile("" ::"v"(warm));
 }
 

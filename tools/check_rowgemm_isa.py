@@ -34,11 +34,6 @@ def regs_of(text):
 
 def check_kernel(name, body):
     lines = body.split("\n")
-    # the residual epilogues (EPI 2, 3) are single-chunk: their row pass follows the last MFMA and the final s_waitcnt
-    # vmcnt(0), nothing is in flight there and the buffer's registers are free for reuse -- check up to the last MFMA only
-    if re.search(r"rowgemm_wd_kernelILi\d+ELi[23]E", name):
-        last = max(i for i, ln in enumerate(lines) if ln.strip().startswith("v_mfma"))
-        lines = lines[:last + 1]
     in_asm = False
     loads = []          # (line index, dest regs)
     for i, ln in enumerate(lines):
@@ -100,6 +95,12 @@ def main():
             print(r.stderr[-3000:])
             return 2
         s = open(out).read()
+        # -S does not run the assembler over the inline asm: an operand the assembler rejects only shows with -c
+        r = subprocess.run([CLANG] + [f for f in FLAGS if f != "-S"] + ["-c", "-o", os.path.join(d, "rowgemm.o"), SRC],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stderr[-3000:])
+            return 2
     n_k = n_bad = 0
     for m in re.finditer(r"^(_ZN2jv\d+(rowgemm_wd_kernel|rowconv_wd_kernel)\w+):\s*;.*?\n(.*?)\.end_amdhsa_kernel", s, re.S | re.M):
         name, body = m.group(1), m.group(3)
