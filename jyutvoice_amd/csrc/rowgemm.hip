@@ -91,11 +91,13 @@ int rowgemm_tile(int M) {
     const long cost = cdivl(wgs, 256) * rt;
     if (!best || cost < best_cost || (cost == best_cost && rt > best)) { best = rt; best_cost = cost; }
   }
-  // measured on the whole path (bench.py, same box, against the tile kernels): 32 utterances x 300 frames (244 workgroups, one
-  // round) -6.3 %, 16 utterances -2.7 %, 8 utterances and 8 x 512 frames a tie, 64 utterances (487 workgroups, two rounds)
-  // +3 %: past one round the tile kernels' many small tiles balance better than two rounds of whole-CU workgroups
+  // measured on the whole path (bench.py, same box, against the tile kernels; W-direct kernel): 4 utterances x 300 frames (77
+  // workgroups of 32 rows) +16 %, 8 (153) -8 %, 16 (122 of 80 rows) -14 %, 32 (244, one round) -9 %, 64 (487, two rounds)
+  // -5.5 %; a forced 80-row tile at 48 utterances (365 workgroups: the second round 43 % full) +4 % -- the cost model
+  // above takes 64-row tiles there (457 workgroups, two rounds 89 % full)
+  // (96: -8.7 %, 48: -3.5 %; 40 utterances, where the model picks two rounds of 48-row tiles: +2.5 % -- left to the tile kernels)
   const int wgs = cdiv(M, 16 * best);
-  if (wgs < 96 || wgs > 256) return 0;
+  if (wgs < 96 || (wgs > 256 && best < 4)) return 0;
   return best;
 }
 
