@@ -30,6 +30,21 @@ int rg_launch_wd(const RowGemmArgs& a, hipStream_t st) {
   return JV_OK;
 }
 
+// A-resident form (rowgemm_wa_kernel): the multi-chunk epilogues when the whole A tile fits beside the slab
+template <int RT, int EPI>
+int rg_launch_wa(const RowGemmArgs& a, hipStream_t st) {
+  static int raised[64] = {};      // per device: the LDS size the attribute was last raised to
+  int dev = 0;
+  JV_HIP(hipGetDevice(&dev));
+  const int lds = rgwa_lds_bytes<RT>(a.K >> 5);
+  if (raised[dev & 63] < lds) {
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_wa_kernel<RT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    raised[dev & 63] = lds;
+  }
+  hipLaunchKernelGGL((rowgemm_wa_kernel<RT, EPI>), dim3(cdiv(a.M, 16 * RT)), dim3(512), lds, st, a);
+  return JV_OK;
+}
+
 template <int RT, int EPI>
 int rg_launch2(const RowGemmArgs& a, hipStream_t st) {
   static bool raised[64] = {};      // per device: the attribute belongs to the kernel's image on the current device
@@ -42,7 +57,11 @@ int rg_launch2(const RowGemmArgs& a, hipStream_t st) {
   }
   const bool prof = prof_on();
   if (prof) prof_begin(st);
-  if (a.Wf && !(a.K & 63) && !dyn_env("JV_RG_WLDS")) JV_TRY((rg_launch_wd<RT, EPI>(a, st)));
+  constexpr bool MULTI = EPI == RG_PLAIN || EPI == RG_GELU_PL || EPI == RG_QKV;
+  const bool wdir = a.Wf && !(a.K & 63) && !dyn_env("JV_RG_WLDS");
+  if (MULTI && wdir && a.N > 256 && rgwa_lds_bytes<RT>(a.K >> 5) <= 160 * 1024 && !dyn_env("JV_RG_NO_ARES")) {
+    if constexpr (MULTI) JV_TRY((rg_launch_wa<RT, EPI>(a, st)));
+  } else if (wdir) JV_TRY((rg_launch_wd<RT, EPI>(a, st)));
   else hipLaunchKernelGGL((rowgemm_kernel<RT, EPI>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rg_lds_bytes<RT>(), st, a);
   if (prof) {
     static const std::string name = std::string("rowgemm_h3<") + std::to_string(16 * RT) + "x256" +

@@ -836,4 +836,246 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wd_kernel(const RowGemmArgs p)
   asm volatile("" ::"v"(warm));
 }
 
+// ---- W-direct with the A tile RESIDENT in LDS: the multi-chunk launches (q|k|v and ff.net.0: K = 256, N = 1536 / 1024) ------
+// rowgemm_wd_kernel streams A through its 3-stage ring once per 256-column chunk: the q|k|v launch fetched 114 MB where
+// its operands are 32 (PMC FETCH_SIZE: the A slices of the ~30 workgroups of an XCD, 2.4 MB, do not survive in a 4 MB L2
+// next to the 120 MB the launch writes).  With K = 256 the whole A tile is 8 steps x 10 KB = 80 KB: it is loaded ONCE,
+// in the prologue, and every chunk reads it in place.  What that removes besides the traffic:
+//   * the A DMA and its counted waits from the main loop (what is waited for is W alone: vmcnt(NWL));
+//   * the workgroup barrier from the main loop -- it existed to publish DMA'd stages and to protect the ring -- so the
+//     eight waves drift apart and one wave's fragment reads / address arithmetic run under another's MFMAs.
+// LDS: 80 KB of A + a slab of ceil(RT / 2) row groups (48 rows, 49 KB) = 130 KB; the chunk epilogue goes through the slab
+// in two passes (row groups [0, GA) then [GA, RT)), four barriers per chunk, none in the loop.
+template <int RT> constexpr int rgwa_ga() { return (RT + 1) / 2; }
+template <int RT> constexpr int rgwa_lds_bytes(int KS) { return KS * rgw_stage_bytes<RT>() + 16 * rgwa_ga<RT>() * RG_SLD * 4; }
+
+template <int EPI, int RPW>
+__device__ __forceinline__ void rg_rows_store(const RowGemmArgs& p, const float* sl, const int trow0, const int srow0, const int m0,
+                                              const int lane, const int c, const int n0, const rg_f32x4 cs4, const rg_f32x4 b4) {
+  static_assert(EPI == RG_PLAIN || EPI == RG_GELU_PL || EPI == RG_QKV, "the residual epilogues are single-chunk: rowgemm_wd_kernel");
+  rg_f32x4 v[RPW];
+  long mrow[RPW];
+  bool ok[RPW];
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    mrow[j] = (long)m0 + trow0 + j;
+    ok[j] = mrow[j] < p.M;
+    v[j] = *reinterpret_cast<const rg_f32x4*>(sl + (srow0 + j) * RG_SLD + 4 * lane) * cs4 + b4;
+  }
+  if (EPI == RG_PLAIN || (EPI == RG_QKV && c < 2)) {      // fp32 rows (q: chunk-uniform branch)
+#pragma unroll
+    for (int j = 0; j < RPW; ++j)
+      if (ok[j]) *reinterpret_cast<rg_f32x4*>(p.out + mrow[j] * p.ldo + n0) = v[j];
+  } else {
+    const float sc = EPI == RG_GELU_PL ? p.out2_scale : (c < 4 ? p.out2_scale : p.out2_scale2);
+    const int col = EPI == RG_GELU_PL ? n0 : n0 - 512;
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      if (!ok[j]) continue;
+      rg_f32x4 t = v[j];
+      if constexpr (EPI == RG_GELU_PL) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = gelu_erf(t[e]);
+      }
+      const Split2 s0 = split2h_pair(t[0] * sc, t[1] * sc);
+      const Split2 s1 = split2h_pair(t[2] * sc, t[3] * sc);
+      unsigned short* o2 = p.out2 + mrow[j] * p.ldo2 + col;
+      *reinterpret_cast<rg_u32x2*>(o2) = rg_u32x2{s0.h, s1.h};
+      *reinterpret_cast<rg_u32x2*>(o2 + p.out2_plane) = rg_u32x2{s0.l, s1.l};
+    }
+  }
+}
+
+template <int RT, int EPI>
+__global__ __launch_bounds__(512, 2) void rowgemm_wa_kernel(const RowGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rg_lds[];
+  constexpr int R = 16 * RT;
+  constexpr int STAGE = rgw_stage_bytes<RT>();
+  constexpr int A_PLANE = R * 64;
+  constexpr int NPIECE = 2 * RT;
+  constexpr int PPW = (NPIECE + 7) / 8;
+  constexpr int NWL = 4;
+  constexpr int GA = rgwa_ga<RT>(), GB = RT - GA;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * R;
+  const int KS = p.K >> 5, NC = p.N >> 8;
+  const int total = KS * NC;
+  float* const slab = reinterpret_cast<float*>(rg_lds + KS * STAGE);
+
+  float warm = 0.f;      // L2 warm-up of the weights (rowgemm_kernel)
+  {
+    const long lpp = ((long)p.N * p.K * 2) >> 7;
+    const int grp = blockIdx.x >> 3, ngrp = (gridDim.x + 7) >> 3;
+    const long per = (2 * lpp + ngrp - 1) / ngrp;
+    const long l = (long)grp * per + tid;
+    if (tid < per && l < 2 * lpp) {
+      const int pl = l >= lpp;
+      warm = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.Wf + (long)pl * p.wf_plane) + ((l - pl * lpp) << 7));
+    }
+  }
+
+  // ---- the whole A tile, once: step ks of every chunk reads stage ks ----
+  {
+    const int prow = lane >> 2, pslot = (lane & 3) ^ rg_key(prow);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave + 8 * i;
+      if (pc < NPIECE) {      // wave-uniform
+        const int pl = pc / RT, g = pc % RT;
+        long row = (long)m0 + g * 16 + prow;
+        row = row < p.a_rows ? row : p.a_rows - 1;
+        const unsigned short* src = p.A2 + (long)pl * p.a2_plane + row * p.lda2 + 8 * pslot;
+        const int dst = pl * A_PLANE + g * 1024;
+        for (int ks = 0; ks < KS; ++ks)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 32 * ks),
+                                           (__attribute__((address_space(3))) void*)(rg_lds + ks * STAGE + dst), 16, 0, 0);
+      }
+    }
+  }
+
+  // ---- W: as in rowgemm_wd_kernel (fragment order, register double buffer loaded by inline asm, counted waits) ----
+  const unsigned short* wbase[2][2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) wbase[nt][pl] = p.Wf + (long)pl * p.wf_plane + ((long)(wave * 2 + nt) * KS) * 512 + lane * 8;
+  long woff = 0;
+  int wk = 0, wc = 0;
+  rg_u32x4 bq[2][2][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bq[i >> 2][(i >> 1) & 1][i & 1] = rg_u32x4{0u, 0u, 0u, 0u};
+  auto load_frag = [](rg_u32x4& dst, const unsigned short* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(ptr) : "memory");
+  };
+  auto load_w = [&](auto par_tag, auto nttag) {
+    constexpr int par = decltype(par_tag)::value, nt = decltype(nttag)::value;
+    load_frag(bq[par][nt][0], wbase[nt][0] + woff);
+    load_frag(bq[par][nt][1], wbase[nt][1] + woff);
+  };
+  auto landed_w = [](rg_u32x4& b00, rg_u32x4& b01, rg_u32x4& b10, rg_u32x4& b11) {
+    asm volatile("" : "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11)::"memory");
+  };
+  auto advance_w = [&]() {      // + 1 KB (512 halves) per step, + 15 KS KB more at a chunk boundary, back to the start after the last chunk
+    const bool wrap = ++wk == KS;
+    if (wrap) {
+      wk = 0;
+      const bool end = ++wc == NC;
+      if (end) wc = 0;
+      woff += end ? 512L + 15L * KS * 512 - 16L * KS * 512 * NC : 512L + 15L * KS * 512;
+    } else {
+      woff += 512L;
+    }
+  };
+  load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+  advance_w();
+  load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+  load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+  advance_w();
+  rg_wait_vmcnt<0>();
+  landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
+  landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
+  rg_barrier();      // every wave's A pieces are in LDS: the only barrier ahead of the epilogues
+
+  const int fslot = (kq ^ rg_key(r16)) << 4;
+  const int a_off = r16 * 64 + fslot;
+  rg_f32x4 acc[RT][2];
+  rg_u32x4 af[2][RT][2];
+  auto read_a = [&](auto par_tag, int stage) {
+    constexpr int par = decltype(par_tag)::value;
+    const unsigned char* const st = rg_lds + stage * STAGE;
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) af[par][mt][pl] = *reinterpret_cast<const rg_u32x4*>(st + a_off + pl * A_PLANE + mt * 1024);
+  };
+  read_a(std::integral_constant<int, 0>{}, 0);
+
+  int ks1 = 1;      // (step + 1) % KS: the stage the next step reads
+  bool waited = false;
+  for (int c = 0; c < NC; ++c) {
+    const int n0 = c * 256 + 4 * lane;
+    rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.colscale + n0);
+    cs4 = cs4 * (1.0f / p.a_scale);
+    rg_f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) b4 = *reinterpret_cast<const rg_f32x4*>(p.bias + n0);
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // One step: block 0, reload bq[par][0] for step s + 2, counted wait, fragments of step s + 1 requested, block 1, reload
+    // bq[par][1].  This wave's memory operations in program order: ... W0(s+1), W1(s+1) | W0(s+2), <wait>, W1(s+2) | ...;
+    // needed at the wait: W0(s+1) and W1(s); behind W0(s+1): W1(s+1) and W0(s+2) = NWL loads.  (The chunk epilogue's loads
+    // and stores only add younger operations: the wait is then stricter than needed, never weaker.)  Past the end of the
+    // launch the loads wrap around to weights that exist (rowgemm_wd_kernel).
+    auto step = [&](auto par_tag) {
+      constexpr int par = decltype(par_tag)::value;
+      auto block = [&](auto nttag) {
+        constexpr int nt = decltype(nttag)::value;
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt) {
+          rg_f32x4 t = acc[mt][nt];
+          auto mm = [&](const rg_u32x4& x, const rg_u32x4& y) {
+            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rg_f16x8, x), __builtin_bit_cast(rg_f16x8, y), t, 0, 0, 0);
+          };
+          mm(af[par][mt][1], bq[par][nt][0]);      // smallest terms first, as the tile kernels do
+          mm(af[par][mt][0], bq[par][nt][1]);
+          mm(af[par][mt][0], bq[par][nt][0]);
+          acc[mt][nt] = t;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(par_tag, nttag);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      block(std::integral_constant<int, 0>{});
+      if (!waited) rg_wait_vmcnt<NWL>();      // (first step of a chunk: waited for ahead of the epilogue's stores, below)
+      waited = false;
+      landed_w(bq[par][1][0], bq[par][1][1], bq[par ^ 1][0][0], bq[par ^ 1][0][1]);
+      read_a(std::integral_constant<int, par ^ 1>{}, ks1);
+      __builtin_amdgcn_sched_barrier(0);
+      block(std::integral_constant<int, 1>{});
+      advance_w();
+      ks1 = ks1 + 1 == KS ? 0 : ks1 + 1;
+    };
+    for (int ks = 0; ks < KS; ks += 2) {
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+    }
+    if (c + 1 < NC) {      // what the next step's wait needs -- W0(s + 1), W1(s) -- has only W1(s + 1) behind it so far
+      rg_wait_vmcnt<2>();
+      waited = true;
+    }
+
+    // ---- the chunk's epilogue: row groups [0, GA) and [GA, RT) through the slab, one pass each ----
+    rg_lds_barrier();      // every wave is done with the previous chunk's slab rows
+#pragma unroll
+    for (int mt = 0; mt < GA; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) slab[(mt * 16 + kq * 4 + e) * RG_SLD + wave * 32 + nt * 16 + r16] = acc[mt][nt][e];
+    rg_lds_barrier();
+    rg_rows_store<EPI, 2 * GA>(p, slab, wave * 2 * GA, wave * 2 * GA, m0, lane, c, n0, cs4, b4);
+    if constexpr (GB > 0) {
+      rg_lds_barrier();
+#pragma unroll
+      for (int mt = 0; mt < GB; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) slab[(mt * 16 + kq * 4 + e) * RG_SLD + wave * 32 + nt * 16 + r16] = acc[GA + mt][nt][e];
+      rg_lds_barrier();
+      rg_rows_store<EPI, 2 * GB>(p, slab, 16 * GA + wave * 2 * GB, wave * 2 * GB, m0, lane, c, n0, cs4, b4);
+    }
+  }
+  // the wrapped-around W loads of the last two steps: bq stays reserved until they have landed (rowgemm_wd_kernel)
+  rg_wait_vmcnt<0>();
+  landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
+  landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
+  asm volatile("" ::"v"(warm));
+}
+
 }  // namespace jv
