@@ -13,7 +13,7 @@ out = sys.argv[1]
 
 def short(name):
     """rocprofv3 kernel name -> the name bench.py's in-library profiler gives the same launches"""
-    m = re.search(r"rowgemm_(?:wd_)?kernel<(\d+), (\d+)>", name)
+    m = re.search(r"rowgemm_(?:wd_|wa_)?kernel<(\d+), (\d+)>", name)
     if m:
         epi = {"0": "", "1": ",gelu", "2": ",res", "3": ",res,ln", "4": ",qkv"}.get(m.group(2), "")
         return f"rowgemm_h3<{16 * int(m.group(1))}x256{epi}>"
