@@ -101,6 +101,7 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   c.no_rowgemm = getenv("JV_NO_ROWGEMM") != nullptr;
   c.no_splitk = getenv("JV_NO_SPLITK") != nullptr;
   c.rg_ff1 = getenv("JV_TILE_FF1") == nullptr;
+  c.no_ffn_fuse = getenv("JV_NO_FFN_FUSE") != nullptr;
   c.no_attn_planes = getenv("JV_NO_ATTN_PLANES") != nullptr;
   c.max_frames = max_frames;
   c.max_tokens = max_tokens;

@@ -19,6 +19,7 @@ namespace jv {
 
 int rowgemm(const RowGemmArgs& a, int epi, hipStream_t st);   // rowgemm.hip
 int rowconv(const RowConvArgs& a, hipStream_t st);
+int rowffn(const RowFfnArgs& a, hipStream_t st);
 int rowgemm_tile(int M);
 
 constexpr int FLOW_G = 4;      // leading guard rows (>= causal left context 2)
@@ -376,6 +377,23 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.ln_g = b.n3.g; a.ln_b = b.n3.b;
     rg_track(a);
     JV_TRY(rowgemm(a, RG_RES_LN, st));
+    if (c.rg_ff1 && !c.no_ffn_fuse && b.ff1.wf && b.ff2.wf && b.ff1.N == 1024 && b.ff1.Cin == 256 && b.ff2.N == 256 && b.ff2.Cin == 1024) {
+      // the feed-forward pair in one launch (rowffn_kernel): the 1024-wide hidden tile never leaves LDS
+      RowFfnArgs f{};
+      f.A2 = reinterpret_cast<const unsigned short*>(w.ln); f.a2_plane = R * 256; f.a_rows = g.a_rows; f.lda2 = 256; f.M = (int)g.M;
+      f.W1f = b.ff1.wf; f.w1f_plane = (long)b.ff1.N * b.ff1.Cin; f.cs1 = b.ff1.colscale; f.b1 = b.ff1.bias; f.a_scale1 = b.ff1.a_scale;
+      f.h_scale = b.ff2.a_scale;
+      f.W2f = b.ff2.wf; f.w2f_plane = (long)b.ff2.N * b.ff2.Cin; f.cs2 = b.ff2.colscale; f.b2 = b.ff2.bias;
+      f.out = out; f.ldo = ldo; f.res = h; f.ldr = 256;
+      f.ln_eps = 1e-5f; f.out2_scale = 1.f;
+      if (!c.exact_range) { f.amax_out = slots_of(out); f.row_slot = w.row_sample; f.row_mask = w.rowmask; }
+      f.alg_rows = (long)g.B2 * g.T;
+      if (next && out == h) {
+        f.ln = 1; f.out2 = reinterpret_cast<unsigned short*>(w.ln); f.out2_plane = R * 256; f.ldo2 = 256; f.out2_scale = next->qkv.a_scale;
+        f.ln_g = next->n1.g; f.ln_b = next->n1.b;
+      }
+      return rowffn(f, st);
+    }
     if (c.rg_ff1) {
       a = rg_args(w.ln, 256, b.ff1);       // ff = gelu(ff.net.0(ln))
       a.out2 = reinterpret_cast<unsigned short*>(w.ff); a.out2_plane = R * 1024; a.ldo2 = 1024; a.out2_scale = b.ff2.a_scale;

@@ -166,6 +166,49 @@ int rowconv(const RowConvArgs& a, hipStream_t st) {
   }
 }
 
+namespace {
+template <int RT>
+int rf_launch(const RowFfnArgs& a, hipStream_t st) {
+  static bool raised[64] = {};
+  int dev = 0;
+  JV_HIP(hipGetDevice(&dev));
+  if (!raised[dev & 63]) {
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowffn_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, rgf_lds_bytes<RT>()));
+    raised[dev & 63] = true;
+  }
+  const bool prof = prof_on();
+  if (prof) prof_begin(st);
+  hipLaunchKernelGGL((rowffn_kernel<RT>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rgf_lds_bytes<RT>(), st, a);
+  if (prof) {
+    static const std::string name = std::string("rowffn_h3<") + std::to_string(16 * RT) + "x256" + ">";
+    const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M);
+    // algorithmic bytes: LayerNorm planes in (rows x 256 x 4 B), both weight matrices, residual in, rows out (+ planes out)
+    prof_end(st, name.c_str(), 2.0 * rows * 2.0 * 256.0 * 1024.0, 4.0 * (rows * 256 * (a.ln ? 4 : 3) + 2.0 * 256 * 1024));
+  }
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+}  // namespace
+
+// out = res + ff.net.2(gelu(ff.net.0(x))) (+ LayerNorm planes of it) in one launch (rowffn_kernel); 256 -> 1024 -> 256 only
+int rowffn(const RowFfnArgs& a, hipStream_t st) {
+  if (a.M <= 0) return JV_OK;
+  if (!a.A2 || !a.W1f || !a.W2f || !a.cs1 || !a.cs2 || !(a.a_scale1 > 0.f) || !(a.h_scale > 0.f) || !a.out || !a.res)
+    return fail(JV_ERR_ARG, "rowffn: needs the operand planes, both weight matrices in fragment order, their scales, out and res");
+  if ((a.lda2 & 7) || (a.ldo & 3) || (a.ldr & 3) || (a.ln && (!a.out2 || (a.ldo2 & 3) || !a.ln_g || !a.ln_b)))
+    return fail(JV_ERR_ARG, "rowffn: aligned strides (and gain / offset / plane buffer for the LayerNorm epilogue) required");
+  int rt = rowgemm_tile(a.M);
+  if (rt == 0) rt = 2;
+  switch (rt) {
+    case 1:
+    case 2: return rf_launch<2>(a, st);
+    case 3: return rf_launch<3>(a, st);
+    case 4: return rf_launch<4>(a, st);
+    case 5: return rf_launch<5>(a, st);
+    default: return fail(JV_ERR_ARG, "rowffn: bad tile height");
+  }
+}
+
 int rowgemm(const RowGemmArgs& a, int epi, hipStream_t st) {
   if (a.M <= 0) return JV_OK;
   if (const char* ab = tuning_env("JV_RG_ABLATE")) const_cast<RowGemmArgs&>(a).ablate = atoi(ab);

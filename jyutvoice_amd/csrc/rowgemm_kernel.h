@@ -1078,4 +1078,341 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wa_kernel(const RowGemmArgs p)
   asm volatile("" ::"v"(warm));
 }
 
+// ---- the feed-forward pair in ONE launch: out = h + ff.net.2(gelu(ff.net.0(x))) (+ the next LayerNorm) ----------------------
+// (jyutvoice/flow/transformer.py:425-443: FeedForward = Linear(256, 1024) -> GELU -> Linear(1024, 256), then the residual)
+// Unfused, ff.net.0 writes its 80 x 1024 hidden tile as planes (80 MB per launch over the batch) and ff.net.2 streams it
+// back through an LDS ring: 160 MB of HBM traffic, one launch ramp and one tail per block more than the arithmetic needs.
+// With the weights out of LDS (W-direct) the tile's two operands fit it exactly: the LayerNorm planes of the 16 RT rows
+// (K = 256: 8 stages, 80 KB at RT = 5) stay resident, and the hidden tile is produced 256 columns at a time straight into
+// a second resident operand image (another 8 stages): 160 KB.  Per hidden chunk c:
+//   phase 1   acc1 = X W1[256 c ..][:]^T             8 steps, A = X (resident), wave w owns hidden columns 32 w .. + 32
+//   GELU      acc1 -> * colscale / a_scale + bias -> exact GELU -> * h_scale -> fp16 planes, written from the MFMA layout
+//             into stage w of the H image (the wave's 32 columns ARE k-step w of phase 2); barrier
+//   phase 2   acc2 += H W2[:, 256 c ..]^T            8 steps, A = H, wave w owns output columns 32 w .. + 32; barrier
+// then ff.net.2's residual (+ LayerNorm) epilogue through a slab laid over both images.  The W fragments of both linears
+// arrive through ONE register double buffer (the step sequence is phase 1, phase 2, phase 1, ... and a step's loads only need
+// an address), waits are counted on W alone, and there is no barrier inside a phase.  K order of every sum is the unfused
+// kernels': bits identical to ff.net.0 -> planes -> ff.net.2 (tests/test_gpu_pipeline.py compares the two paths with torch.equal).
+struct RowFfnArgs {
+  const unsigned short* A2;      // LayerNorm planes [2][a_rows][lda2] of x * a_scale1 (K = 256)
+  long a2_plane, a_rows;
+  int lda2, M;
+  const unsigned short* W1f;     // ff.net.0 (N = 1024, K = 256) in fragment order, plane stride w1f_plane halves
+  long w1f_plane;
+  const float *cs1, *b1;
+  float a_scale1, h_scale;       // h_scale: the power of two the hidden planes are scaled with (= ff.net.2's a_scale)
+  const unsigned short* W2f;     // ff.net.2 (N = 256, K = 1024) in fragment order
+  long w2f_plane;
+  const float *cs2, *b2;
+  float* out;                    // fp32 rows
+  long ldo;
+  const float* res;
+  long ldr;
+  unsigned short* out2;          // LN != 0: LayerNorm planes [2][rows][ldo2] of the stored row * out2_scale
+  long out2_plane;
+  int ldo2, ln;
+  float out2_scale;
+  const float *ln_g, *ln_b;
+  float ln_eps;
+  float* amax_out;
+  const int* row_slot;
+  const unsigned char* row_mask;
+  long alg_rows;
+};
+
+template <int RT> constexpr int rgf_lds_bytes() { return 16 * rgw_stage_bytes<RT>() > 16 * RT * RG_SLD * 4 ? 16 * rgw_stage_bytes<RT>() : 16 * RT * RG_SLD * 4; }
+
+template <int RT>
+__global__ __launch_bounds__(512, 2) void rowffn_kernel(const RowFfnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rg_lds[];
+  constexpr int R = 16 * RT;
+  constexpr int STAGE = rgw_stage_bytes<RT>();
+  constexpr int A_PLANE = R * 64;
+  constexpr int NPIECE = 2 * RT;
+  constexpr int PPW = (NPIECE + 7) / 8;
+  constexpr int NWL = 4;
+  constexpr int KS = 8, NCH = 4;      // K = 256 per phase, 4 hidden chunks of 256
+  constexpr int H_OFF = KS * STAGE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * R;
+
+  float warm = 0.f;      // L2 warm-up of both weight matrices (2 planes x 512 KB each: 16384 lines)
+  {
+    const long lines = 16384;
+    const int grp = blockIdx.x >> 3, ngrp = (gridDim.x + 7) >> 3;
+    const long per = (lines + ngrp - 1) / ngrp;
+    const long l = (long)grp * per + tid;
+    if (tid < per && l < lines) {
+      const int which = (int)(l >> 13), pl = (int)(l >> 12) & 1;      // 4096 lines per plane
+      const unsigned short* base = which ? p.W2f + (long)pl * p.w2f_plane : p.W1f + (long)pl * p.w1f_plane;
+      warm = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + ((l & 4095) << 7));
+    }
+  }
+
+  // ---- X: the whole A tile, once ----
+  {
+    const int prow = lane >> 2, pslot = (lane & 3) ^ rg_key(prow);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave + 8 * i;
+      if (pc < NPIECE) {
+        const int pl = pc / RT, g = pc % RT;
+        long row = (long)m0 + g * 16 + prow;
+        row = row < p.a_rows ? row : p.a_rows - 1;
+        const unsigned short* src = p.A2 + (long)pl * p.a2_plane + row * p.lda2 + 8 * pslot;
+        const int dst = pl * A_PLANE + g * 1024;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 32 * ks),
+                                           (__attribute__((address_space(3))) void*)(rg_lds + ks * STAGE + dst), 16, 0, 0);
+      }
+    }
+  }
+
+  // ---- W of both linears through one register double buffer ----
+  const unsigned short* w1base[2][2];
+  const unsigned short* w2base[2][2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      w1base[nt][pl] = p.W1f + (long)pl * p.w1f_plane + ((long)(wave * 2 + nt) * 8) * 512 + lane * 8;
+      w2base[nt][pl] = p.W2f + (long)pl * p.w2f_plane + ((long)(wave * 2 + nt) * 32) * 512 + lane * 8;
+    }
+  long off1 = 0, off2 = 0;      // halves: where the NEXT step to load sits in W1f / W2f
+  int wph = 0, wk = 0, wcc = 0; // its phase, k-step, chunk
+  rg_u32x4 bq[2][2][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bq[i >> 2][(i >> 1) & 1][i & 1] = rg_u32x4{0u, 0u, 0u, 0u};
+  auto load_frag = [](rg_u32x4& dst, const unsigned short* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(ptr) : "memory");
+  };
+  auto load_w = [&](auto par_tag, auto nttag) {
+    constexpr int par = decltype(par_tag)::value, nt = decltype(nttag)::value;
+    load_frag(bq[par][nt][0], wph ? w2base[nt][0] + off2 : w1base[nt][0] + off1);
+    load_frag(bq[par][nt][1], wph ? w2base[nt][1] + off2 : w1base[nt][1] + off1);
+  };
+  auto landed_w = [](rg_u32x4& b00, rg_u32x4& b01, rg_u32x4& b10, rg_u32x4& b11) {
+    asm volatile("" : "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11)::"memory");
+  };
+  auto advance_w = [&]() {
+    // W1f: block (16 c + 2 wave + nt), k-step ks -> ((16 c) 8 + ks) 512 halves past the base; W2f: k-step 8 c + ks
+    if (wph == 0) off1 += 512; else off2 += 512;
+    if (++wk == KS) {
+      wk = 0;
+      if (wph == 0) {
+        off1 += 120L * 512;      // next chunk's blocks: + 16 blocks x 8 steps, less the 8 just walked
+        wph = 1;
+      } else {
+        wph = 0;
+        if (++wcc == NCH) { wcc = 0; off1 = 0; off2 = 0; }      // past the end: wrap around to weights that exist
+      }
+    }
+  };
+  load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+  advance_w();
+  load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+  load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+  advance_w();
+  rg_wait_vmcnt<0>();
+  landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
+  landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
+  rg_barrier();      // X is in LDS for every wave
+
+  const int fslot = (kq ^ rg_key(r16)) << 4;
+  const int a_off = r16 * 64 + fslot;
+  rg_f32x4 acc1[RT][2], acc2[RT][2];
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc2[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // one 32-deep step of either phase: A fragments read here (no cross-step prefetch: phase 2's operand does not exist
+  // until the barrier in front of it), block 0, reload, counted wait (W alone: see rowgemm_wa_kernel), block 1, reload
+  auto step = [&](auto par_tag, rg_f32x4 (&acc)[RT][2], const unsigned char* st) {
+    constexpr int par = decltype(par_tag)::value;
+    rg_u32x4 af[RT][2];
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) af[mt][pl] = *reinterpret_cast<const rg_u32x4*>(st + a_off + pl * A_PLANE + mt * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    auto block = [&](auto nttag) {
+      constexpr int nt = decltype(nttag)::value;
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt) {
+        rg_f32x4 t = acc[mt][nt];
+        auto mm = [&](const rg_u32x4& x, const rg_u32x4& y) {
+          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rg_f16x8, x), __builtin_bit_cast(rg_f16x8, y), t, 0, 0, 0);
+        };
+        mm(af[mt][1], bq[par][nt][0]);      // smallest terms first, as everywhere
+        mm(af[mt][0], bq[par][nt][1]);
+        mm(af[mt][0], bq[par][nt][0]);
+        acc[mt][nt] = t;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(par_tag, nttag);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    block(std::integral_constant<int, 0>{});
+    rg_wait_vmcnt<NWL>();
+    landed_w(bq[par][1][0], bq[par][1][1], bq[par ^ 1][0][0], bq[par ^ 1][0][1]);
+    block(std::integral_constant<int, 1>{});
+    advance_w();
+  };
+
+  const float inv1 = 1.0f / p.a_scale1;
+  for (int c = 0; c < NCH; ++c) {
+    // ---- phase 1: the hidden chunk ----
+    const int hc0 = c * 256 + wave * 32 + r16;      // this lane's hidden columns: hc0 (nt = 0), hc0 + 16 (nt = 1)
+    float csl[2], bl[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      csl[nt] = p.cs1[hc0 + 16 * nt] * inv1;
+      bl[nt] = p.b1 ? p.b1[hc0 + 16 * nt] : 0.f;
+    }
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ks += 2) {
+      step(std::integral_constant<int, 0>{}, acc1, rg_lds + ks * STAGE);
+      step(std::integral_constant<int, 1>{}, acc1, rg_lds + (ks + 1) * STAGE);
+    }
+    // ---- GELU -> planes, into stage `wave` of H (rows mt 16 + 4 kq + e, k = 16 nt + r16 of that stage) ----
+    if (c > 0) rg_lds_barrier();      // every wave is done reading the previous chunk's H
+    {
+      unsigned char* const hs = rg_lds + H_OFF + wave * STAGE;
+      const int key = (kq & 1) << 1;      // rg_key(row): bit 2 of the row = bit 0 of kq
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int slot = (2 * nt + (r16 >> 3)) ^ key;
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const float g0 = gelu_erf(acc1[mt][nt][e] * csl[nt] + bl[nt]) * p.h_scale;
+            const float g1 = gelu_erf(acc1[mt][nt][e + 1] * csl[nt] + bl[nt]) * p.h_scale;
+            const Split2 sp = split2h_pair(g0, g1);
+            const int row = mt * 16 + kq * 4 + e;
+            unsigned char* d = hs + row * 64 + (slot << 4) + (r16 & 7) * 2;
+            *reinterpret_cast<unsigned short*>(d) = (unsigned short)(sp.h & 0xffffu);
+            *reinterpret_cast<unsigned short*>(d + 64) = (unsigned short)(sp.h >> 16);
+            *reinterpret_cast<unsigned short*>(d + A_PLANE) = (unsigned short)(sp.l & 0xffffu);
+            *reinterpret_cast<unsigned short*>(d + A_PLANE + 64) = (unsigned short)(sp.l >> 16);
+          }
+        }
+    }
+    rg_lds_barrier();      // H complete
+    // ---- phase 2 ----
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ks += 2) {
+      step(std::integral_constant<int, 0>{}, acc2, rg_lds + H_OFF + ks * STAGE);
+      step(std::integral_constant<int, 1>{}, acc2, rg_lds + H_OFF + (ks + 1) * STAGE);
+    }
+  }
+
+  // ---- ff.net.2's epilogue: + bias + residual -> rows (+ tracking) (-> LayerNorm -> planes); rowgemm_wd_kernel's ----
+  constexpr int NRW = 2 * RT;
+  rg_f32x4 rpre[NRW];
+  unsigned seenpre[NRW];
+  bool trkpre[NRW];
+#pragma unroll
+  for (int j = 0; j < NRW; ++j) {
+    const long mr0 = (long)m0 + wave * NRW + j;
+    const long mr = mr0 < p.M ? mr0 : (long)p.M - 1;
+    rpre[j] = *reinterpret_cast<const rg_f32x4*>(p.res + mr * p.ldr + 4 * lane);
+    trkpre[j] = false;
+    seenpre[j] = 0xffffffffu;
+  }
+  if (p.amax_out) {
+    int slot[NRW];
+#pragma unroll
+    for (int j = 0; j < NRW; ++j) {
+      const long mr0 = (long)m0 + wave * NRW + j;
+      const long mr = mr0 < p.M ? mr0 : (long)p.M - 1;
+      trkpre[j] = mr0 < p.M && (!p.row_mask || p.row_mask[mr] != 0);
+      slot[j] = p.row_slot ? p.row_slot[mr] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < NRW; ++j) seenpre[j] = *reinterpret_cast<const unsigned*>(p.amax_out + slot[j]);
+  }
+  rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.cs2 + 4 * lane);
+  cs4 = cs4 * (1.0f / p.h_scale);
+  rg_f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.b2) b4 = *reinterpret_cast<const rg_f32x4*>(p.b2 + 4 * lane);
+  rg_f32x4 gg = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
+  if (p.ln) {
+    gg = *reinterpret_cast<const rg_f32x4*>(p.ln_g + 4 * lane);
+    bb = *reinterpret_cast<const rg_f32x4*>(p.ln_b + 4 * lane);
+  }
+  rg_lds_barrier();      // every wave is done with X and H: the slab goes over them
+  float* const big = reinterpret_cast<float*>(rg_lds);
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) big[(mt * 16 + kq * 4 + e) * RG_SLD + wave * 32 + nt * 16 + r16] = acc2[mt][nt][e];
+  rg_lds_barrier();
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    rg_f32x4 v[RT];
+    long mrow[RT];
+    bool ok[RT];
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+      const int trow = wave * NRW + ps * RT + j;
+      mrow[j] = (long)m0 + trow;
+      ok[j] = mrow[j] < p.M;
+      v[j] = *reinterpret_cast<const rg_f32x4*>(big + trow * RG_SLD + 4 * lane) * cs4 + b4;
+      v[j] += rpre[ps * RT + j];
+      if (ok[j]) *reinterpret_cast<rg_f32x4*>(p.out + mrow[j] * p.ldo + 4 * lane) = v[j];
+    }
+    if (p.amax_out) {
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        unsigned u = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u = max(u, __float_as_uint(v[j][e]) & 0x7fffffffu);
+        if (trkpre[ps * RT + j] && __builtin_amdgcn_ballot_w64(u > seenpre[ps * RT + j]) != 0) {
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o));
+          if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(p.amax_out + (p.row_slot ? p.row_slot[mrow[j]] : 0)), u);
+        }
+      }
+    }
+    if (p.ln) {
+      float sum[RT], sq[RT];
+#pragma unroll
+      for (int j = 0; j < RT; ++j) sum[j] = wave_sum((v[j][0] + v[j][1]) + (v[j][2] + v[j][3]));
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        const rg_f32x4 d = v[j] - sum[j] * (1.f / 256.f);
+        sq[j] = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+      }
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        if (!ok[j]) continue;
+        const float mean = sum[j] * (1.f / 256.f);
+        const float rstd = 1.0f / sqrtf(sq[j] * (1.f / 256.f) + p.ln_eps);
+        const rg_f32x4 y = (v[j] - mean) * rstd * gg + bb;
+        const Split2 s0 = split2h_pair(y[0] * p.out2_scale, y[1] * p.out2_scale);
+        const Split2 s1 = split2h_pair(y[2] * p.out2_scale, y[3] * p.out2_scale);
+        unsigned short* o2 = p.out2 + mrow[j] * p.ldo2 + 4 * lane;
+        *reinterpret_cast<rg_u32x2*>(o2) = rg_u32x2{s0.h, s1.h};
+        *reinterpret_cast<rg_u32x2*>(o2 + p.out2_plane) = rg_u32x2{s0.l, s1.l};
+      }
+    }
+  }
+  rg_wait_vmcnt<0>();      // the wrapped-around W loads: bq stays reserved until they have landed
+  landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
+  landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
+  asm volatile("" ::"v"(warm));
+}
+
 }  // namespace jv

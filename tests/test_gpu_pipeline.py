@@ -292,3 +292,26 @@ def test_full_size_engines_cross_check(models):
     finally:
         get_runtime("cuda:0").ensure(32, 300, 150).set_exact_range(False)
         tts.load_state_dict(synth.tts_state_dict())
+
+
+def test_fused_feed_forward_equals_two_launches(monkeypatch):
+    """rowffn_kernel (ff.net.0 -> GELU -> ff.net.2 + residual (+ LayerNorm) in one launch, the hidden tile kept in LDS)
+    against the two row-owning launches it replaces (JV_NO_FFN_FUSE=1): same K order in every sum, same GELU, same plane
+    split -- the mels must be equal bit for bit, at a tile height of 5 (32 utterances) and of 2 (ragged 8)"""
+    import jyutvoice_amd
+    from jyutvoice_amd import synth
+    sd = synth.tts_state_dict(fixed_duration=1.5)
+    keys = ("x", "x_lengths", "lang", "tone", "word_pos", "syllable_pos", "spk_embed")
+    cases = [synth.batch(32, 150), synth.batch(8, 150, first_index=40, lengths=[150 - 11 * i for i in range(8)])]
+
+    def run():
+        tts, _ = jyutvoice_amd.build_default("cuda:0")
+        tts.load_state_dict(sd)
+        return [tts.synthesise(*[b[k] for k in keys], None, n_timesteps=2, batched=True)["mel"].cpu() for b in cases]
+
+    fused = run()
+    monkeypatch.setenv("JV_NO_FFN_FUSE", "1")
+    split = run()
+    for f, s in zip(fused, split):
+        assert torch.isfinite(f).all()
+        assert torch.equal(f, s), float((f - s).abs().max())

@@ -17,6 +17,9 @@ def short(name):
     if m:
         epi = {"0": "", "1": ",gelu", "2": ",res", "3": ",res,ln", "4": ",qkv"}.get(m.group(2), "")
         return f"rowgemm_h3<{16 * int(m.group(1))}x256{epi}>"
+    m = re.search(r"rowffn_kernel<(\d+)>", name)
+    if m:
+        return f"rowffn_h3<{16 * int(m.group(1))}x256>"
     m = re.search(r"rowconv_kernel<(\d+)>", name)
     if m:
         return f"rowconv_h3<{16 * int(m.group(1))}x256,k3>"
