@@ -1230,15 +1230,21 @@ __global__ __launch_bounds__(512, 2) void rowffn_kernel(const RowFfnArgs p) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) acc2[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // one 32-deep step of either phase: A fragments read here (no cross-step prefetch: phase 2's operand does not exist
-  // until the barrier in front of it), block 0, reload, counted wait (W alone: see rowgemm_wa_kernel), block 1, reload
-  auto step = [&](auto par_tag, rg_f32x4 (&acc)[RT][2], const unsigned char* st) {
+  // one 32-deep step of either phase: block 0, reload, counted wait (W alone: see rowgemm_wa_kernel), the NEXT step's A
+  // fragments requested into the other register set (their LDS latency hides behind block 1), block 1, reload.  `have`: this
+  // step's fragments were requested by the previous step; `st_next` = null where the next step's operand does not exist
+  // yet (the last step of phase 1: H is only complete behind the barrier)
+  rg_u32x4 af[2][RT][2];
+  auto read_a = [&](auto par_tag, const unsigned char* st) {
     constexpr int par = decltype(par_tag)::value;
-    rg_u32x4 af[RT][2];
 #pragma unroll
     for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) af[mt][pl] = *reinterpret_cast<const rg_u32x4*>(st + a_off + pl * A_PLANE + mt * 1024);
+      for (int pl = 0; pl < 2; ++pl) af[par][mt][pl] = *reinterpret_cast<const rg_u32x4*>(st + a_off + pl * A_PLANE + mt * 1024);
+  };
+  auto step = [&](auto par_tag, rg_f32x4 (&acc)[RT][2], const unsigned char* st, const unsigned char* st_next, const bool have) {
+    constexpr int par = decltype(par_tag)::value;
+    if (!have) read_a(par_tag, st);
     __builtin_amdgcn_sched_barrier(0);
     auto block = [&](auto nttag) {
       constexpr int nt = decltype(nttag)::value;
@@ -1248,9 +1254,9 @@ __global__ __launch_bounds__(512, 2) void rowffn_kernel(const RowFfnArgs p) {
         auto mm = [&](const rg_u32x4& x, const rg_u32x4& y) {
           t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rg_f16x8, x), __builtin_bit_cast(rg_f16x8, y), t, 0, 0, 0);
         };
-        mm(af[mt][1], bq[par][nt][0]);      // smallest terms first, as everywhere
-        mm(af[mt][0], bq[par][nt][1]);
-        mm(af[mt][0], bq[par][nt][0]);
+        mm(af[par][mt][1], bq[par][nt][0]);      // smallest terms first, as everywhere
+        mm(af[par][mt][0], bq[par][nt][1]);
+        mm(af[par][mt][0], bq[par][nt][0]);
         acc[mt][nt] = t;
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1260,6 +1266,8 @@ __global__ __launch_bounds__(512, 2) void rowffn_kernel(const RowFfnArgs p) {
     block(std::integral_constant<int, 0>{});
     rg_wait_vmcnt<NWL>();
     landed_w(bq[par][1][0], bq[par][1][1], bq[par ^ 1][0][0], bq[par ^ 1][0][1]);
+    if (st_next) read_a(std::integral_constant<int, par ^ 1>{}, st_next);
+    __builtin_amdgcn_sched_barrier(0);
     block(std::integral_constant<int, 1>{});
     advance_w();
   };
@@ -1280,8 +1288,8 @@ __global__ __launch_bounds__(512, 2) void rowffn_kernel(const RowFfnArgs p) {
       for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int ks = 0; ks < KS; ks += 2) {
-      step(std::integral_constant<int, 0>{}, acc1, rg_lds + ks * STAGE);
-      step(std::integral_constant<int, 1>{}, acc1, rg_lds + (ks + 1) * STAGE);
+      step(std::integral_constant<int, 0>{}, acc1, rg_lds + ks * STAGE, rg_lds + (ks + 1) * STAGE, ks > 0 || c > 0);
+      step(std::integral_constant<int, 1>{}, acc1, rg_lds + (ks + 1) * STAGE, ks + 2 < KS ? rg_lds + (ks + 2) * STAGE : nullptr, true);
     }
     // ---- GELU -> planes, into stage `wave` of H (rows mt 16 + 4 kq + e, k = 16 nt + r16 of that stage) ----
     if (c > 0) rg_lds_barrier();      // every wave is done reading the previous chunk's H
@@ -1311,8 +1319,10 @@ __global__ __launch_bounds__(512, 2) void rowffn_kernel(const RowFfnArgs p) {
     // ---- phase 2 ----
 #pragma unroll 1
     for (int ks = 0; ks < KS; ks += 2) {
-      step(std::integral_constant<int, 0>{}, acc2, rg_lds + H_OFF + ks * STAGE);
-      step(std::integral_constant<int, 1>{}, acc2, rg_lds + H_OFF + (ks + 1) * STAGE);
+      step(std::integral_constant<int, 0>{}, acc2, rg_lds + H_OFF + ks * STAGE, rg_lds + H_OFF + (ks + 1) * STAGE, ks > 0);
+      // (the last step of the chunk requests the first X stage of the next chunk's phase 1: X is always there)
+      step(std::integral_constant<int, 1>{}, acc2, rg_lds + H_OFF + (ks + 1) * STAGE,
+           ks + 2 < KS ? rg_lds + H_OFF + (ks + 2) * STAGE : (c + 1 < NCH ? rg_lds : nullptr), true);
     }
   }
 
