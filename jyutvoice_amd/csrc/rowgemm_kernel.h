@@ -843,48 +843,10 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wd_kernel(const RowGemmArgs p)
 // in the prologue, and every chunk reads it in place.  What that removes besides the traffic:
 //   * the A DMA and its counted waits from the main loop (what is waited for is W alone: vmcnt(NWL));
 //   * the workgroup barrier from the main loop -- it existed to publish DMA'd stages and to protect the ring -- so the
-//     eight waves drift apart and one wave's fragment reads / address arithmetic run under another's MFMAs.
-// LDS: 80 KB of A + a slab of ceil(RT / 2) row groups (48 rows, 49 KB) = 130 KB; the chunk epilogue goes through the slab
-// in two passes (row groups [0, GA) then [GA, RT)), four barriers per chunk, none in the loop.
-template <int RT> constexpr int rgwa_ga() { return (RT + 1) / 2; }
-template <int RT> constexpr int rgwa_lds_bytes(int KS) { return KS * rgw_stage_bytes<RT>() + 16 * rgwa_ga<RT>() * RG_SLD * 4; }
-
-template <int EPI, int RPW>
-__device__ __forceinline__ void rg_rows_store(const RowGemmArgs& p, const float* sl, const int trow0, const int srow0, const int m0,
-                                              const int lane, const int c, const int n0, const rg_f32x4 cs4, const rg_f32x4 b4) {
-  static_assert(EPI == RG_PLAIN || EPI == RG_GELU_PL || EPI == RG_QKV, "the residual epilogues are single-chunk: rowgemm_wd_kernel");
-  rg_f32x4 v[RPW];
-  long mrow[RPW];
-  bool ok[RPW];
-#pragma unroll
-  for (int j = 0; j < RPW; ++j) {
-    mrow[j] = (long)m0 + trow0 + j;
-    ok[j] = mrow[j] < p.M;
-    v[j] = *reinterpret_cast<const rg_f32x4*>(sl + (srow0 + j) * RG_SLD + 4 * lane) * cs4 + b4;
-  }
-  if (EPI == RG_PLAIN || (EPI == RG_QKV && c < 2)) {      // fp32 rows (q: chunk-uniform branch)
-#pragma unroll
-    for (int j = 0; j < RPW; ++j)
-      if (ok[j]) *reinterpret_cast<rg_f32x4*>(p.out + mrow[j] * p.ldo + n0) = v[j];
-  } else {
-    const float sc = EPI == RG_GELU_PL ? p.out2_scale : (c < 4 ? p.out2_scale : p.out2_scale2);
-    const int col = EPI == RG_GELU_PL ? n0 : n0 - 512;
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-      if (!ok[j]) continue;
-      rg_f32x4 t = v[j];
-      if constexpr (EPI == RG_GELU_PL) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = gelu_erf(t[e]);
-      }
-      const Split2 s0 = split2h_pair(t[0] * sc, t[1] * sc);
-      const Split2 s1 = split2h_pair(t[2] * sc, t[3] * sc);
-      unsigned short* o2 = p.out2 + mrow[j] * p.ldo2 + col;
-      *reinterpret_cast<rg_u32x2*>(o2) = rg_u32x2{s0.h, s1.h};
-      *reinterpret_cast<rg_u32x2*>(o2 + p.out2_plane) = rg_u32x2{s0.l, s1.l};
-    }
-  }
-}
+//     eight waves drift apart and one wave's fragment reads / address arithmetic / chunk epilogue run under another's MFMAs.
+// LDS: 80 KB of A + eight 16 x 36-float patches (one per wave, 18 KB) through which each wave transposes its own 32 columns
+// of a chunk for the row-wise stores: no barrier in the chunk epilogues either -- the prologue's is the only one.
+template <int RT> constexpr int rgwa_lds_bytes(int KS) { return KS * rgw_stage_bytes<RT>() + 8 * 16 * 36 * 4; }
 
 template <int RT, int EPI>
 __global__ __launch_bounds__(512, 2) void rowgemm_wa_kernel(const RowGemmArgs p) {
@@ -895,7 +857,6 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wa_kernel(const RowGemmArgs p)
   constexpr int NPIECE = 2 * RT;
   constexpr int PPW = (NPIECE + 7) / 8;
   constexpr int NWL = 4;
-  constexpr int GA = rgwa_ga<RT>(), GB = RT - GA;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kq = lane >> 4;
@@ -996,11 +957,6 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wa_kernel(const RowGemmArgs p)
   int ks1 = 1;      // (step + 1) % KS: the stage the next step reads
   bool waited = false;
   for (int c = 0; c < NC; ++c) {
-    const int n0 = c * 256 + 4 * lane;
-    rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.colscale + n0);
-    cs4 = cs4 * (1.0f / p.a_scale);
-    rg_f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) b4 = *reinterpret_cast<const rg_f32x4*>(p.bias + n0);
 #pragma unroll
     for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
@@ -1049,26 +1005,46 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wa_kernel(const RowGemmArgs p)
       waited = true;
     }
 
-    // ---- the chunk's epilogue: row groups [0, GA) and [GA, RT) through the slab, one pass each ----
-    rg_lds_barrier();      // every wave is done with the previous chunk's slab rows
+    // ---- the chunk's epilogue, per wave: no workgroup barrier, so one wave's stores and GELU run under the others' MFMAs.
+    // A wave owns 32 columns of the chunk; 16 rows at a time go through its private 16 x 36-float patch of LDS (MFMA layout
+    // in: lane = column, 4 rows; rows out: 8 lanes x 16 B per row), so that every store instruction writes whole 128-byte
+    // (fp32) / 64-byte (fp16 plane) row segments.  LDS executes one wave's accesses in order: its reads see its writes.
+    {
+      float* const ws = slab + wave * (16 * 36);
+      const int prow = lane >> 3, pc4 = (lane & 7) * 4;      // this lane's row of an 8-row pass, its 4 columns of the 32
+      const int nw = c * 256 + wave * 32 + pc4;
+      rg_f32x4 cw = *reinterpret_cast<const rg_f32x4*>(p.colscale + nw);
+      cw = cw * (1.0f / p.a_scale);
+      rg_f32x4 bw = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bw = *reinterpret_cast<const rg_f32x4*>(p.bias + nw);
 #pragma unroll
-    for (int mt = 0; mt < GA; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) slab[(mt * 16 + kq * 4 + e) * RG_SLD + wave * 32 + nt * 16 + r16] = acc[mt][nt][e];
-    rg_lds_barrier();
-    rg_rows_store<EPI, 2 * GA>(p, slab, wave * 2 * GA, wave * 2 * GA, m0, lane, c, n0, cs4, b4);
-    if constexpr (GB > 0) {
-      rg_lds_barrier();
-#pragma unroll
-      for (int mt = 0; mt < GB; ++mt)
+      for (int mt = 0; mt < RT; ++mt) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) slab[(mt * 16 + kq * 4 + e) * RG_SLD + wave * 32 + nt * 16 + r16] = acc[GA + mt][nt][e];
-      rg_lds_barrier();
-      rg_rows_store<EPI, 2 * GB>(p, slab, 16 * GA + wave * 2 * GB, wave * 2 * GB, m0, lane, c, n0, cs4, b4);
+          for (int e = 0; e < 4; ++e) ws[(kq * 4 + e) * 36 + nt * 16 + r16] = acc[mt][nt][e];
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int trow = mt * 16 + ps * 8 + prow;
+          const long mrow = (long)m0 + trow;
+          rg_f32x4 v = *reinterpret_cast<const rg_f32x4*>(ws + (ps * 8 + prow) * 36 + pc4) * cw + bw;
+          if (mrow >= p.M) continue;
+          if (EPI == RG_PLAIN || (EPI == RG_QKV && c < 2)) {
+            *reinterpret_cast<rg_f32x4*>(p.out + mrow * p.ldo + nw) = v;
+          } else {
+            const float sc = EPI == RG_GELU_PL ? p.out2_scale : (c < 4 ? p.out2_scale : p.out2_scale2);
+            if constexpr (EPI == RG_GELU_PL) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            }
+            const Split2 s0 = split2h_pair(v[0] * sc, v[1] * sc);
+            const Split2 s1 = split2h_pair(v[2] * sc, v[3] * sc);
+            unsigned short* o2 = p.out2 + mrow * p.ldo2 + (EPI == RG_GELU_PL ? nw : nw - 512);
+            *reinterpret_cast<rg_u32x2*>(o2) = rg_u32x2{s0.h, s1.h};
+            *reinterpret_cast<rg_u32x2*>(o2 + p.out2_plane) = rg_u32x2{s0.l, s1.l};
+          }
+        }
+      }
     }
   }
   // the wrapped-around W loads of the last two steps: bq stays reserved until they have landed (rowgemm_wd_kernel)
