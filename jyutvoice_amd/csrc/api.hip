@@ -458,7 +458,8 @@ int jv_op_rowconv(const float* A, int64_t rows, int M, int Cin, const float* W, 
   static void* scratch = nullptr;
   static size_t cap = 0;
   const size_t n = (size_t)N * K;
-  const size_t need = n * 4 + (size_t)N * 12 + 256 + (size_t)rows * sizeof(int);
+  const size_t head = ((n * 4 + (size_t)N * 12 + 256 + (size_t)rows * sizeof(int)) + 255) & ~(size_t)255;
+  const size_t need = head + n * 4;      // + the planes again in fragment order
   if (need > cap) {
     if (scratch) (void)hipFree(scratch);
     JV_HIP(hipMalloc(&scratch, need));
@@ -467,11 +468,15 @@ int jv_op_rowconv(const float* A, int64_t rows, int M, int Cin, const float* W, 
   unsigned short* planes = static_cast<unsigned short*>(scratch);
   float* cs = reinterpret_cast<float*>(static_cast<char*>(scratch) + ((n * 4 + 63) & ~(size_t)63));
   int* slots = reinterpret_cast<int*>(cs + 3 * N + 16);
+  unsigned short* wf = reinterpret_cast<unsigned short*>(static_cast<char*>(scratch) + head);
   JV_TRY(jv::split2h_planes(W, N, K, cs + N, planes, cs, st));
+  const bool frag = !((Cin >> 5) & 1) && !(Cin & 31);
+  if (frag) JV_TRY(jv::pack_wfrag(planes, (long)n, K, N, K, wf, (long)n, st));
   JV_HIP(hipMemsetAsync(slots, 0, (size_t)rows * sizeof(int), st));
   jv::RowConvArgs a{};
   a.A = A; a.lda = Cin; a.a_rows = rows; a.M = M; a.Cin = Cin; a.rowmask_in = rowmask;
   a.W2 = planes; a.w2_plane = (long)n; a.ldw = K; a.colscale = cs; a.amax_in = amax_in; a.row_slot = slots; a.bias = bias;
+  if (frag) { a.Wf = wf; a.wf_plane = (long)n; }
   a.out = out; a.ldo = N;
   if (ln_g) { a.ln = 1; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f; }
   a.act = act; a.rowmask_out = rowmask; a.rowvec = rowvec; a.rowvec_ld = N; a.res = res; a.ldr = N;

@@ -234,6 +234,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     RowConvArgs r{};
     r.A = a.A; r.lda = a.lda; r.a_rows = a.a_rows; r.M = a.M; r.Cin = a.Cin; r.rowmask_in = a.rowmask_in;
     r.W2 = m.w2; r.w2_plane = (long)m.n_rows * m.ldw; r.ldw = m.ldw; r.colscale = m.colscale;
+    r.Wf = m.wf; r.wf_plane = (long)m.N * m.ntaps * m.Cin;
     r.amax_in = a.amax_in; r.row_slot = w.row_sample; r.bias = a.bias;
     r.out = a.out; r.ldo = a.ldo;
     r.ln = a.ln; r.ln_g = a.ln_g; r.ln_b = a.ln_b; r.ln_eps = a.ln_eps; r.act = a.act; r.rowmask_out = a.rowmask_out;

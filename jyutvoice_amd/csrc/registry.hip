@@ -430,11 +430,13 @@ struct Packer {
   }
   // ... and a second copy of the planes in fragment order for the row-owning GEMM (rowgemm_kernel.h, W-direct)
   void wfrag(GemmW& g) {
-    if (!g.w2 || rc != JV_OK || g.ntaps != 1 || (g.N & 255) || (g.Cin & 63) || g.ldw != g.Cin) return;
-    const long n = (long)g.N * g.Cin;
+    // linears (K = Cin) and the trunk's k = 3 convolutions (K = 3 Cin, tap-major columns: rowconv_wd_kernel)
+    const int K = g.ntaps * g.Cin;
+    if (!g.w2 || rc != JV_OK || (g.ntaps != 1 && g.ntaps != 3) || (g.N & 255) || (g.Cin & 63) || g.ldw != K) return;
+    const long n = (long)g.N * K;
     float* d = alloc((size_t)n + 8);
     if (!d) return;
-    if (pack_wfrag(g.w2, (long)g.n_rows * g.ldw, g.ldw, g.N, g.Cin, reinterpret_cast<unsigned short*>(d), n, st) != JV_OK) {
+    if (pack_wfrag(g.w2, (long)g.n_rows * g.ldw, g.ldw, g.N, K, reinterpret_cast<unsigned short*>(d), n, st) != JV_OK) {
       rc = JV_ERR_HIP;
       return;
     }
@@ -594,6 +596,7 @@ int finalize_model(Context& c, int model, hipStream_t st) {
       // fp16x3 with the measured bound of the residual stream (flow.hip)
       (void)pk.half3(e.res[i].block1);
       (void)pk.half3(e.res[i].block2);
+      pk.wfrag(e.res[i].block1); pk.wfrag(e.res[i].block2);
       (void)pk.half3(e.res[i].res);
       for (int j = 0; j < EST_NBLK; ++j) {
         const std::string b = stage[i] + "1." + S(j) + ".";
@@ -644,6 +647,7 @@ int finalize_model(Context& c, int model, hipStream_t st) {
     (void)pk.half3(e.up_conv);
     (void)pk.half3(e.final_conv);
     (void)pk.half3(e.final_proj);
+    pk.wfrag(e.down_conv); pk.wfrag(e.up_conv); pk.wfrag(e.final_conv);
 
     // ---------------- text encoder + duration predictor ----------------
     EncoderW& n = c.enc;

@@ -24,6 +24,8 @@ struct RowConvArgs {
   const unsigned short* W2;      // fp16 planes [2][256][ldw] of W[n][j Cin + ci] * 2^e_n, colscale[n] = 2^-e_n
   long w2_plane;
   int ldw;
+  const unsigned short* Wf;      // the same planes in MFMA-fragment order (pack_wfrag over K = 3 Cin; rowconv_wd_kernel); null: W2 by LDS-DMA
+  long wf_plane;
   const float* colscale;
   const float* amax_in;          // per-utterance bound of A (slot = row_slot[row])
   const int* row_slot;
@@ -336,5 +338,295 @@ __global__ __launch_bounds__(512, 2) void rowconv_kernel(const RowConvArgs p) {
   }
   asm volatile("" ::"v"(warm));
 }
+
+// ---- W-direct form (see rowgemm_wd_kernel): weights in fragment order through a register double buffer, LDS holds the two
+// A window buffers, the row facts and a slab of its own; one workgroup barrier per 32-channel chunk instead of one per step
+template <int RT> constexpr int rcw_slab_off() { return (2 * 2 * rc_a_plane<RT>() + 16 * RT * 8 + 255) & ~255; }
+template <int RT> constexpr int rcw_lds_bytes() { return rcw_slab_off<RT>() + 16 * RT * RG_SLD * 4; }
+
+template <int RT>
+__global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rc_lds[];
+  constexpr int R = 16 * RT, WR = R + 2;
+  constexpr int A_PLANE = rc_a_plane<RT>(), A_BUF = 2 * A_PLANE, A_OFF = 0;
+  constexpr int NI = (WR * 8 + 511) / 512;      // float4 per thread per chunk (window rows x 8 float4)
+  constexpr int NWL = 4;                        // weight loads per wave and step: 2 column blocks x 2 planes
+  constexpr int SLAB_OFF = rcw_slab_off<RT>();
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * R;
+  const int NCH = p.Cin >> 5;
+  const int total = 3 * NCH;
+
+  // warm this XCD's L2 with the weight planes (see rowgemm_kernel.h)
+  float warm = 0.f;
+  {
+    const long lpp = ((long)256 * 3 * p.Cin * 2) >> 7;
+    const int grp = blockIdx.x >> 3, ngrp = (gridDim.x + 7) >> 3;
+    const long per = (2 * lpp + ngrp - 1) / ngrp;
+    const long l = (long)grp * per + tid;
+    if (tid < per && l < 2 * lpp) {
+      const int pl = l >= lpp;
+      warm = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.Wf + (long)pl * p.wf_plane) + ((l - pl * lpp) << 7));
+    }
+  }
+
+  // ---- W: fragment order over K = 3 Cin (k = j Cin + 32 c is fragment step j NCH + c), a register double buffer loaded by
+  // inline asm with counted waits -- rowgemm_wd_kernel's, including its rules (tools/check_rowgemm_isa.py covers this kernel)
+  const int KSW = 3 * NCH;
+  const unsigned short* wbase[2][2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) wbase[nt][pl] = p.Wf + (long)pl * p.wf_plane + ((long)(wave * 2 + nt) * KSW) * 512 + lane * 8;
+  long woff = 0;       // halves: fragment step of the NEXT step to load, x 512
+  int wj = 0, wc = 0;  // its tap and chunk
+  rg_u32x4 bq[2][2][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bq[i >> 2][(i >> 1) & 1][i & 1] = rg_u32x4{0u, 0u, 0u, 0u};
+  auto load_frag = [](rg_u32x4& dst, const unsigned short* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(ptr) : "memory");
+  };
+  auto load_w = [&](auto par_tag, auto nttag) {
+    constexpr int par = decltype(par_tag)::value, nt = decltype(nttag)::value;
+    load_frag(bq[par][nt][0], wbase[nt][0] + woff);
+    load_frag(bq[par][nt][1], wbase[nt][1] + woff);
+  };
+  auto landed_w = [](rg_u32x4& b00, rg_u32x4& b01, rg_u32x4& b10, rg_u32x4& b11) {
+    asm volatile("" : "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11)::"memory");
+  };
+  auto advance_w = [&]() {      // (c, j) -> (c, j + 1): + NCH steps; (c, 2) -> (c + 1, 0): + 1 - 2 NCH; past the end: back to 0
+    if (++wj == 3) {
+      wj = 0;
+      if (++wc == NCH) { wc = 0; woff = 0; }
+      else woff += (1L - 2L * NCH) * 512;
+    } else {
+      woff += (long)NCH * 512;
+    }
+  };
+  // The weights start first: everything below (row slots -> measured bounds -> first A window) is a chain of dependent
+  // global loads, several microseconds that the first two steps' fragments spend in flight
+  load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+  advance_w();
+  load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+  load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+  advance_w();
+
+  // ---- per-row facts of this tile, read once here (two dependent loads per row) and kept in LDS for the epilogue:
+  // x = bits of 1 / a_scale of the row's utterance, y = its slot | flags
+  int2* const rowinfo = reinterpret_cast<int2*>(rc_lds + A_OFF + 2 * A_BUF);      // 8 R bytes, then the slab
+  constexpr int RI_KEEP = 1 << 29, RI_TRACK = 1 << 30;
+  if (tid < R) {
+    const long m = (long)m0 + tid;
+    int y = 0;
+    float inv = 0.f;
+    if (m < p.M) {
+      const int sl = p.row_slot[m];
+      inv = 1.0f / h3_scale_dev(p.amax_in[sl]);
+      y = sl;
+      if (!p.rowmask_out || p.rowmask_out[m] != 0) y |= RI_KEEP;
+      if (p.amax_out && (!p.row_mask || p.row_mask[m] != 0)) y |= RI_TRACK;
+    }
+    rowinfo[tid] = int2{(int)__float_as_uint(inv), y};
+  }
+
+  // ---- A window staging: thread -> (window row, float4) pairs, fixed over the chunks
+  const float* asrc[NI];
+  int astep[NI], adst[NI];
+  float ascale[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int idx = tid + 512 * i;
+    const int r = idx >> 3, c4 = idx & 7;
+    const long ar = (long)m0 - 2 + r;
+    bool ok = r < WR && ar >= 0 && ar < p.a_rows;
+    if (ok && p.rowmask_in) ok = p.rowmask_in[ar] != 0;
+    asrc[i] = ok ? p.A + ar * p.lda + 4 * c4 : rc_zero_page;
+    astep[i] = ok ? 1 : 0;
+    ascale[i] = ok ? h3_scale_dev(p.amax_in[p.row_slot[ar]]) : 0.f;
+    adst[i] = r < WR ? r * 64 + ((((c4 >> 1) ^ rg_key(r)) << 4) | ((c4 & 1) << 3)) : -1;
+  }
+  rg_f32x4 pa[NI];
+  auto load_A = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)      // explicitly GLOBAL loads: a generic pointer (A or the zero page) would make them flat_load, which
+                                      // counts on lgkmcnt as well and returns out of order -- no counted wait is valid beside it
+      pa[i] = *(const __attribute__((address_space(1))) rg_f32x4*)(asrc[i] + c * 32 * astep[i]);
+  };
+  auto store_A = [&](int buf) {
+    unsigned char* const base = rc_lds + A_OFF + buf * A_BUF;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (adst[i] >= 0) {
+        const Split2 s0 = split2h_pair(pa[i][0] * ascale[i], pa[i][1] * ascale[i]);
+        const Split2 s1 = split2h_pair(pa[i][2] * ascale[i], pa[i][3] * ascale[i]);
+        *reinterpret_cast<rg_u32x2*>(base + adst[i]) = rg_u32x2{s0.h, s1.h};
+        *reinterpret_cast<rg_u32x2*>(base + A_PLANE + adst[i]) = rg_u32x2{s0.l, s1.l};
+      }
+    }
+  };
+
+  rg_f32x4 acc[RT][2];
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // the epilogue's per-column constants, fetched here so that their latency is not paid behind the main loop
+  const rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.colscale + 4 * lane);
+  rg_f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) b4 = *reinterpret_cast<const rg_f32x4*>(p.bias + 4 * lane);
+  rg_f32x4 gg = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
+  if (p.ln) {
+    gg = *reinterpret_cast<const rg_f32x4*>(p.ln_g + 4 * lane);
+    bb = *reinterpret_cast<const rg_f32x4*>(p.ln_b + 4 * lane);
+  }
+  load_A(0);
+  store_A(0);
+  if (NCH > 1) load_A(1);
+  // both steps' fragments (and everything older) have landed once only the A loads of chunk 1 are outstanding
+  if (NCH > 1) rg_wait_vmcnt<NI>(); else rg_wait_vmcnt<0>();
+  landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
+  landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
+
+  // One step = (chunk c, tap j): block 0 (column block 0 x all row groups, A fragments at row offset j of the chunk's window),
+  // reload bq[par][0] for step s + 2, counted wait, block 1, reload bq[par][1].  This wave's vector-memory operations in
+  // program order: ... W0(s+1), W1(s+1) [A loads of chunk c + 2, behind step (c, 0)] | W0(s+2), <wait>, W1(s+2) ...; needed at
+  // the wait: W0(s+1) and W1(s); behind W0(s+1): W1(s+1), the A loads where step s - 1 issued them, W0(s+2).  The window
+  // changes per CHUNK, not per step: one workgroup barrier per chunk (three in the LDS-ring form, whose weight stages
+  // needed one per step).  Past the end of the launch the W loads wrap around to weights that exist.
+  auto step = [&](auto par_tag, const int c, const int j) {
+    constexpr int par = decltype(par_tag)::value;
+    if (j == 0) {
+      rg_lds_barrier();      // every thread's plane stores of this chunk's window are complete; the other buffer is free
+      if (c + 1 < NCH) store_A((c + 1) & 1);      // its registers were loaded a chunk ago
+    }
+    const unsigned char* const sa = rc_lds + A_OFF + (c & 1) * A_BUF;
+    rg_u32x4 af[RT][2];
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt) {
+      const int row = mt * 16 + r16 + j;
+      const int a_off = row * 64 + ((kq ^ rg_key(row)) << 4);
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) af[mt][pl] = *reinterpret_cast<const rg_u32x4*>(sa + pl * A_PLANE + a_off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    auto block = [&](auto nttag) {
+      constexpr int nt = decltype(nttag)::value;
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt) {
+        rg_f32x4 t = acc[mt][nt];
+        auto mm = [&](const rg_u32x4& x, const rg_u32x4& y) {
+          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rg_f16x8, x), __builtin_bit_cast(rg_f16x8, y), t, 0, 0, 0);
+        };
+        mm(af[mt][1], bq[par][nt][0]);
+        mm(af[mt][0], bq[par][nt][1]);
+        mm(af[mt][0], bq[par][nt][0]);
+        acc[mt][nt] = t;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(par_tag, nttag);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    block(std::integral_constant<int, 0>{});
+    if (j == 1 && c + 2 < NCH) rg_wait_vmcnt<NWL + NI>(); else rg_wait_vmcnt<NWL>();
+    landed_w(bq[par][1][0], bq[par][1][1], bq[par ^ 1][0][0], bq[par ^ 1][0][1]);
+    block(std::integral_constant<int, 1>{});
+    advance_w();
+    if (j == 0 && c + 2 < NCH) load_A(c + 2);      // behind this step's weight loads (the wait counts above rely on it)
+  };
+#pragma unroll 1
+  for (int c = 0; c < NCH; c += 2) {      // NCH is even: two chunks = six steps, parities 0 1 0 1 0 1
+    step(std::integral_constant<int, 0>{}, c, 0);
+    step(std::integral_constant<int, 1>{}, c, 1);
+    step(std::integral_constant<int, 0>{}, c, 2);
+    step(std::integral_constant<int, 1>{}, c + 1, 0);
+    step(std::integral_constant<int, 0>{}, c + 1, 1);
+    step(std::integral_constant<int, 1>{}, c + 1, 2);
+  }
+
+  // ---- epilogue: the whole tile through ONE slab laid over the (now idle) weight ring -- a single chunk has nothing left to
+  // prefetch -- then 2 RT rows per wave, RT at a time so that their loads, reductions and transcendentals overlap.  (In 32-row
+  // passes through a slab of their own, two barriers each, the tail took 13 - 19 us of a 50 us launch.)
+  if (JV_ABLATE(p, 16)) return;
+  const bool mish = p.act == ACT_MISH;      // (uniform) the one activation the estimator uses here
+  float* const slab = reinterpret_cast<float*>(rc_lds + SLAB_OFF);      // its own region: nothing to wait for before writing it
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) slab[(mt * 16 + kq * 4 + e) * RG_SLD + wave * 32 + nt * 16 + r16] = acc[mt][nt][e];
+  rg_lds_barrier();
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    constexpr int RPW = RT;      // rows per wave and group: the wave owns tile rows 2 RT wave ... 2 RT wave + 2 RT - 1
+    rg_f32x4 v[RPW], r[RPW], rv[RPW];
+    long mrow[RPW];
+    bool ok[RPW], keep[RPW], tracked[RPW];
+    unsigned seen[RPW];
+    int slot[RPW];
+#pragma unroll
+    for (int jj = 0; jj < RPW; ++jj) {
+      const int trow = wave * 2 * RT + ps * RT + jj;
+      mrow[jj] = (long)m0 + trow;
+      ok[jj] = mrow[jj] < p.M;
+      const int2 ri = rowinfo[trow];
+      slot[jj] = ri.y & (RI_KEEP - 1);
+      const float inv = ok[jj] ? __uint_as_float((unsigned)ri.x) : 0.f;      // 1 / the power of two its window rows were staged with
+      v[jj] = *reinterpret_cast<const rg_f32x4*>(slab + trow * RG_SLD + 4 * lane) * (cs4 * inv) + b4;
+      keep[jj] = ok[jj] && (ri.y & RI_KEEP) != 0;
+      r[jj] = (p.res && ok[jj]) ? *reinterpret_cast<const rg_f32x4*>(p.res + mrow[jj] * p.ldr + 4 * lane) : rg_f32x4{0.f, 0.f, 0.f, 0.f};
+      rv[jj] = (p.rowvec && ok[jj]) ? *reinterpret_cast<const rg_f32x4*>(p.rowvec + (long)slot[jj] * p.rowvec_ld + 4 * lane)
+                                    : rg_f32x4{0.f, 0.f, 0.f, 0.f};
+      tracked[jj] = ok[jj] && (ri.y & RI_TRACK) != 0;
+      seen[jj] = 0xffffffffu;
+      if (tracked[jj]) seen[jj] = *reinterpret_cast<const unsigned*>(p.amax_out + slot[jj]);
+    }
+    if (p.ln) {
+      float sum[RPW], sq[RPW];
+#pragma unroll
+      for (int jj = 0; jj < RPW; ++jj) sum[jj] = wave_sum((v[jj][0] + v[jj][1]) + (v[jj][2] + v[jj][3]));
+#pragma unroll
+      for (int jj = 0; jj < RPW; ++jj) {
+        const rg_f32x4 d = v[jj] - sum[jj] * (1.f / 256.f);
+        sq[jj] = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+      }
+#pragma unroll
+      for (int jj = 0; jj < RPW; ++jj) {
+        const float mean = sum[jj] * (1.f / 256.f);
+        const float rstd = 1.0f / sqrtf(sq[jj] * (1.f / 256.f) + p.ln_eps);
+        v[jj] = (v[jj] - mean) * rstd * gg + bb;
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < RPW; ++jj) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[jj][e] = keep[jj] ? (mish ? mish_fast(v[jj][e]) : act_apply(v[jj][e], p.act)) : 0.f;
+      v[jj] = (v[jj] + rv[jj]) + r[jj];
+      if (ok[jj]) *reinterpret_cast<rg_f32x4*>(p.out + mrow[jj] * p.ldo + 4 * lane) = v[jj];
+    }
+    if (p.amax_out) {
+#pragma unroll
+      for (int jj = 0; jj < RPW; ++jj) {
+        unsigned u = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u = max(u, __float_as_uint(v[jj][e]) & 0x7fffffffu);
+        if (tracked[jj] && __builtin_amdgcn_ballot_w64(u > seen[jj]) != 0) {
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o));
+          if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(p.amax_out + slot[jj]), u);
+        }
+      }
+    }
+  }
+  rg_wait_vmcnt<0>();      // the wrapped-around W loads: bq stays reserved until they have landed (rowgemm_wd_kernel)
+  landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
+  landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
+  asm volatile("" ::"v"(warm));
+}
+
 
 }  // namespace jv

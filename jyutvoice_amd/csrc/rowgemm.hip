@@ -131,9 +131,17 @@ int rc_launch(const RowConvArgs& a, hipStream_t st) {
                                rc_lds_bytes<RT>()));
     raised[dev & 63] = true;
   }
+  static bool raised_wd[64] = {};
+  const bool wdir = a.Wf && !((a.Cin >> 5) & 1) && !dyn_env("JV_RG_WLDS");      // W-direct: an even number of 32-channel chunks
+  if (wdir && !raised_wd[dev & 63]) {
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowconv_wd_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               rcw_lds_bytes<RT>()));
+    raised_wd[dev & 63] = true;
+  }
   const bool prof = prof_on();
   if (prof) prof_begin(st);
-  hipLaunchKernelGGL((rowconv_kernel<RT>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rc_lds_bytes<RT>(), st, a);
+  if (wdir) hipLaunchKernelGGL((rowconv_wd_kernel<RT>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rcw_lds_bytes<RT>(), st, a);
+  else hipLaunchKernelGGL((rowconv_kernel<RT>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rc_lds_bytes<RT>(), st, a);
   if (prof) {
     static const std::string name = std::string("rowconv_h3<") + std::to_string(16 * RT) + "x256,k3>";
     const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M);
