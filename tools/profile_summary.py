@@ -20,7 +20,7 @@ def short(name):
     m = re.search(r"rowffn_kernel<(\d+)>", name)
     if m:
         return f"rowffn_h3<{16 * int(m.group(1))}x256>"
-    m = re.search(r"rowconv_kernel<(\d+)>", name)
+    m = re.search(r"rowconv_(?:wd_)?kernel<(\d+)>", name)
     if m:
         return f"rowconv_h3<{16 * int(m.group(1))}x256,k3>"
     m = re.search(r"attn64_pl_kernel<(\d)>", name)
