@@ -65,10 +65,10 @@ __device__ __forceinline__ void pl_wait_vmcnt() {
 __device__ __forceinline__ void pl_barrier() { asm volatile("s_barrier" ::: "memory"); }
 __device__ __forceinline__ void pl_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void attn64_pl_kernel(const AttnArgs p) {
+template <int NW, int NST>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (NST == 2 ? 4 : 3)) void attn64_pl_kernel(const AttnArgs p) {
   // the ring, reused at the end for the [2 planes][32 NW queries][128 B] output image
-  constexpr int LDS_BYTES = PL_NSTAGE * PL_STAGE > 2 * 32 * NW * 128 ? PL_NSTAGE * PL_STAGE : 2 * 32 * NW * 128;
+  constexpr int LDS_BYTES = NST * PL_STAGE > 2 * 32 * NW * 128 ? NST * PL_STAGE : 2 * 32 * NW * 128;
   __shared__ __attribute__((aligned(256))) unsigned char lds[LDS_BYTES];
   constexpr int PPW = 16 / NW;      // DMA pieces per wave and key tile
   const int tid = threadIdx.x, lane = tid & 63;
@@ -152,17 +152,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void attn64_pl_kernel(con
   float m_run = -INFINITY, l_run = 0.f;
 
   if (nkt > 0) issue(0, 0);
-  if (nkt > 1) issue(32, 1);
+  if (NST > 2 && nkt > 1) issue(32, 1);
   // per-lane read offsets
   const int k_off = r32 * 128;                                   // + pl * PL_PLANE + slot
   const int vq = (lane & 15) >> 2, vp = lane & 3, vg = (lane >> 4) & 1;      // transposed read: block row, 8-byte piece, 16-d group
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * 32;
-    if (kt + 1 < nkt) pl_wait_vmcnt<PPW>(); else pl_wait_vmcnt<0>();
+    // NST = 3: tile kt has landed when only tile kt + 1's pieces are outstanding; tile kt + 2 goes into the stage tile kt - 1
+    // left.  NST = 2 (32 KB: four workgroups per CU instead of three): nothing else is in flight at the wait, and tile kt + 1
+    // is issued behind the barrier into the stage tile kt - 1 left
+    if (NST > 2 && kt + 1 < nkt) pl_wait_vmcnt<PPW>(); else pl_wait_vmcnt<0>();
     pl_barrier();
-    if (kt + 2 < nkt) issue(k0 + 64, (kt + 2) % PL_NSTAGE);
+    if (NST > 2) { if (kt + 2 < nkt) issue(k0 + 64, (kt + 2) % NST); }
+    else if (kt + 1 < nkt) issue(k0 + 32, (kt + 1) % NST);
     if (!active) continue;
-    const unsigned char* const sK = lds + (kt % PL_NSTAGE) * PL_STAGE;
+    const unsigned char* const sK = lds + (kt % NST) * PL_STAGE;
     const unsigned char* const sV = sK + 2 * PL_PLANE;
     // S^T[key][query] = sum_d K[key][d] * Q[query][d]
     f32x16 s;
@@ -287,9 +291,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void attn64_pl_kernel(con
   }
 }
 
-template <int NW>
+template <int NW, int NST = PL_NSTAGE>
 void launch_pl(const AttnArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL((attn64_pl_kernel<NW>), dim3(cdiv(a.L, 32 * NW) * a.H * a.B), dim3(64 * NW), 0, st, a);
+  hipLaunchKernelGGL((attn64_pl_kernel<NW, NST>), dim3(cdiv(a.L, 32 * NW) * a.H * a.B), dim3(64 * NW), 0, st, a);
 }
 
 }  // namespace
@@ -306,7 +310,12 @@ int attention64_planes(const AttnArgs& a, hipStream_t st) {
   if (const char* f = dyn_env("JV_ATTN_NW")) nw = atoi(f);
   switch (nw) {
     case 2: launch_pl<2>(a, st); break;
-    case 4: launch_pl<4>(a, st); break;
+    case 4:
+      // two stages (32 KB, <= 128 VGPRs): four workgroups per CU instead of three -- the fourth hides more of the others'
+      // barriers and softmax chains than the third stage hid of the DMA latency (175.1 -> 171.7 ms per pass, same box)
+      if (dyn_env("JV_ATTN_NST3")) launch_pl<4, 3>(a, st);
+      else launch_pl<4, 2>(a, st);
+      break;
     default: launch_pl<8>(a, st); break;
   }
   if (prof) {
