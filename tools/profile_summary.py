@@ -23,7 +23,7 @@ def short(name):
     m = re.search(r"rowconv_(?:wd_)?kernel<(\d+)>", name)
     if m:
         return f"rowconv_h3<{16 * int(m.group(1))}x256,k3>"
-    m = re.search(r"attn64_pl_kernel<(\d)>", name)
+    m = re.search(r"attn64_pl_kernel<(\d)(?:, \d)?>", name)
     if m:
         return f"attn64_pl<{m.group(1)} waves>"
     m = re.search(r"conv_gemm_x6_kernel<(\d+), (\d+), \d+, \d+, (\d), (\d), (\d)(?:, (\d+))?(?:, (\d+))?>", name)
