@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Build-time check of the hand-managed register double buffer in rowgemm_wd_kernel / rowconv (rowgemm_kernel.h).
+"""Build-time check of the hand-managed register double buffer of the W-direct kernels: rowgemm_wd_kernel, rowgemm_wa_kernel,
+rowffn_kernel (rowgemm_kernel.h) and rowconv_wd_kernel (rowconv_kernel.h).
 
 The weight fragments are loaded by inline asm (global_load_dwordx4) and waited for by a counted s_waitcnt the compiler does
 not know about.  That is only sound if, in the generated code, the destination registers of those loads are touched by
