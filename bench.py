@@ -36,19 +36,28 @@ HBM_PEAK_GBS = 8000.0
 
 
 def pmc_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/profile.sh: rocprofv3 --pmc FETCH_SIZE, doubled
-    as MI355X_MICROARCH.md prescribes for gfx950, and --pmc WRITE_SIZE; counters cannot be read from inside this process).
-    Only quoted for the workload those passes ran (the default C3 shape); null otherwise."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
-    if (args.batch, args.tokens, args.timesteps) != (32, 150, 10) or not os.path.exists(path):
-        return {}
-    with open(path) as fh:
-        d = json.load(fh)
-    k = d["kernels"].get(kernel)
-    if not k or "fetch_bytes" not in k or "write_bytes" not in k:
-        return {}
-    return {"traffic": k["fetch_bytes"] + k["write_bytes"], "traffic_fetch": k["fetch_bytes"], "traffic_write": k["write_bytes"],
-            "traffic_source": "profiles/r02_pmc_traffic.json <- " + d["source"]}
+    """HBM bytes per launch of `kernel` from a committed PMC pass (tools/profile.sh: rocprofv3 --pmc FETCH_SIZE, doubled as
+    MI355X_MICROARCH.md prescribes for gfx950, and --pmc WRITE_SIZE; counters cannot be read from inside this process).
+    Quoted only for the workload those passes ran (the default C3 shape) AND only when the file was measured on this very
+    build: profiles/rNN_pmc_traffic.json carries the hash of the kernel sources (jyutvoice_amd.build.source_hash) and a
+    kernel edited since makes `traffic` null instead of silently stale."""
+    import glob
+
+    from jyutvoice_amd.build import source_hash
+    if (args.batch, args.tokens, args.timesteps) != (32, 150, 10) or args.strong:
+        return {"traffic_note": "PMC passes exist for the default C3 shape only"}
+    here, want = os.path.dirname(os.path.abspath(__file__)), source_hash()
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        with open(path) as fh:
+            d = json.load(fh)
+        if d.get("csrc_sha16") != want:
+            continue
+        k = d["kernels"].get(kernel)
+        if not k or "fetch_bytes" not in k or "write_bytes" not in k:
+            continue
+        return {"traffic": k["fetch_bytes"] + k["write_bytes"], "traffic_fetch": k["fetch_bytes"], "traffic_write": k["write_bytes"],
+                "traffic_source": f"profiles/{os.path.basename(path)} (csrc_sha16 {want}) <- " + d["source"]}
+    return {"traffic_note": f"no PMC pass under profiles/ was measured on this build (csrc_sha16 {want}): run tools/profile.sh"}
 
 
 def kernel_peak(name: str):
@@ -58,7 +67,7 @@ def kernel_peak(name: str):
         # the dense bf16 MFMA peak / 6
         return BF16_MFMA_PEAK_TFLOPS / 6.0, ("fp32 operands split into 3 bf16 planes, 6 x v_mfma_f32_32x32x16_bf16 per product, "
                                              "fp32 accumulate; peak = dense bf16 MFMA (2500) / 6")
-    if name.startswith(("conv_gemm_h3", "attn64_h3", "attn64_pl", "rowgemm_h3", "rowconv_h3", "rowffn_h3")):
+    if name.startswith(("conv_gemm_h3", "attn64_h3", "attn64_pl", "rowgemm_h3", "rowconv_h3", "rowffn_h3", "rowblock_h3")):
         # fp16x3: three fp16 MFMA products per fp32-accurate multiply-add (fp16 and bf16 MFMA rates are equal)
         return BF16_MFMA_PEAK_TFLOPS / 3.0, ("fp32 operands scaled by an exact power of two and split into 2 fp16 planes (22 bits), "
                                              "3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; peak = dense fp16 MFMA (2500) / 3")
@@ -78,13 +87,26 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(n_tokens: int, n_timesteps: int, repeats: int, hip=None):
-    """the oracle on the host: B = 1 sequential semantics (what the reference does), end to end.
-    hip (optional): {"mel" [B,80,T], "wav" [B,480T], "s" [B,1,480T]} CPU tensors of the benchmarked pass; utterance i of
-    the batch is the oracle's utterance i (same seeded inputs), so the timed oracle runs double as the parity check --
-    mel max-abs against the oracle's mel, waveform RMS against the oracle's vocoder on the HIP mel with the HIP source
-    signal (outside the timed part)."""
+    """The oracle on the host, as BASELINE.md 3 plans it: B = 1 sequential semantics (what the reference does), end to end,
+    for (a) ONE utterance of the benchmarked shape (C3: 150 tokens -> 300 frames) and (b) configs[0] (C1: 64 tokens -> 128
+    frames); per stage (encoder + duration predictor + length regulation, CFM loop, HiFT) and total; 1 warm-up, then the
+    median of `repeats` runs (each of another utterance of the same shape: utterance i of the batch is the oracle's
+    utterance i, same seeded inputs, so the timed runs double as the parity check).
+    hip (optional): {"mel" [B,80,T], "wav" [B,480T], "s" [B,1,480T]} CPU tensors of the benchmarked pass -- mel max-abs against
+    the oracle's mel, waveform RMS against the oracle's vocoder on the HIP mel with the HIP source signal (outside the timed part)."""
     import math
+    import statistics
 
     import torch
 
@@ -95,44 +117,56 @@ def cpu_baseline(n_tokens: int, n_timesteps: int, repeats: int, hip=None):
     tts_sd, hift_sd, noise = synth.tts_state_dict(fixed_duration=1.5), synth.hift_state_dict(), synth.rand_noise()
     w = ohift.fold_weight_norm(hift_sd)
     g = torch.Generator().manual_seed(0)
+    mels = {}
 
-    def one(i):
-        u = synth.batch(1, n_tokens, first_index=i)
+    def one(i, tokens, keep):
+        tm = {}
+        u = synth.batch(1, tokens, first_index=i)
+        t0 = time.perf_counter()
         res = otts.synthesise(tts_sd, noise, u["x"], u["x_lengths"], u["lang"], u["tone"], u["word_pos"], u["syllable_pos"],
-                              u["spk_embed"], None, n_timesteps=n_timesteps)
+                              u["spk_embed"], None, n_timesteps=n_timesteps, timings=tm)
         mel = res["mel"]
         T = mel.shape[2]
+        t1 = time.perf_counter()
         f0 = ohift.f0_predict(w, mel)
         phase = (torch.rand(1, 9, 1, generator=g) * 2 - 1) * math.pi
         phase[:, 0] = 0
         s = ohift.source(w, f0, phase, torch.randn(1, 9, 480 * T, generator=g))
         ohift.decode(w, mel, s)
-        mels[i] = mel
-        return T
+        t2 = time.perf_counter()
+        if keep:
+            mels[i] = mel
+        return {"frames": T, "encoder_dp": tm["encoder_dp"], "cfm": tm["cfm"], "hift": t2 - t1, "total": t2 - t0}
 
-    mels = {}
+    def config(tokens, keep):
+        one(0, tokens, keep)                      # warm-up
+        runs = [one(1 + i, tokens, keep) for i in range(repeats)]
+        med = {k: statistics.median(r[k] for r in runs) for k in ("encoder_dp", "cfm", "hift", "total")}
+        T = runs[0]["frames"]
+        return {"tokens": tokens, "frames": T, "ms": {k: round(1e3 * v, 1) for k, v in med.items()},
+                "frames_per_s": round(T / med["total"], 2), "rtf": round(med["total"] / (T * 0.02), 4)}, sum(r["total"] for r in runs)
+
     with torch.inference_mode():
-        one(0)                      # warm-up
-        t0 = time.perf_counter()
-        frames = sum(one(1 + i) for i in range(repeats))
-        dt = time.perf_counter() - t0
+        c3, cpu_s3 = config(n_tokens, True)
+        c1, cpu_s1 = config(64, False)
         parity = None
         if hip is not None:
             mel_err = wav_err = 0.0
-            for i, m in mels.items():
-                if i >= hip["mel"].shape[0]:
-                    continue
-                mel_err = max(mel_err, float((hip["mel"][i:i + 1] - m).abs().max()))
+            checked = sorted(i for i in mels if i < hip["mel"].shape[0])
+            for i in checked:
+                mel_err = max(mel_err, float((hip["mel"][i:i + 1] - mels[i]).abs().max()))
                 want = ohift.decode(w, hip["mel"][i:i + 1], hip["s"][i:i + 1])
                 wav_err = max(wav_err, float((hip["wav"][i:i + 1] - want).pow(2).mean().sqrt()))
-            parity = {"mel_max_abs": float(f"{mel_err:.3e}"), "wav_rms": float(f"{wav_err:.3e}"),
-                      "utterances": sorted(i for i in mels if i < hip["mel"].shape[0]),
-                      "tolerance": {"mel_max_abs": 1e-3, "wav_rms": 1e-4},
+            tol = {"mel_max_abs": 1e-3, "wav_rms": 1e-4}
+            parity = {"mel_max_abs": float(f"{mel_err:.3e}"), "wav_rms": float(f"{wav_err:.3e}"), "utterances": checked, "tolerance": tol,
+                      "ok": bool(checked) and mel_err <= tol["mel_max_abs"] and wav_err <= tol["wav_rms"],
                       "against": "CPU oracle (oracle/, B = 1 per utterance): its mel; its vocoder on the HIP mel with the HIP source signal"}
-    out = {"value": round(frames / dt, 2), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
-           "rtf": round(dt / (frames * 0.02), 4),
-           "sample": f"{repeats} utterances x {n_tokens} tokens -> {frames // repeats} frames, n_timesteps={n_timesteps}, "
-                     f"B=1 sequential, encoder+CFM+HiFT, after 1 warm-up"}
+    out = {"value": c3["frames_per_s"], "unit": "mel-frames/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(), "kind": "port",
+           "rtf": c3["rtf"],
+           "sample": f"one utterance of the benchmarked shape ({n_tokens} tokens -> {c3['frames']} frames) and one of configs[0] (64 tokens -> "
+                     f"{c1['frames']} frames), n_timesteps={n_timesteps}, B=1 sequential, encoder+CFM+HiFT end to end, 1 warm-up then the "
+                     f"median of {repeats} runs each ({cpu_s3 + cpu_s1:.1f} s of timed CPU work); `value` is the benchmarked shape's",
+           "c3_utterance": c3, "c1": c1}
     return out, parity
 
 
@@ -153,7 +187,11 @@ def main():
                          "steps instrumented lowers `value` by ~5 %%; one step gives ~1700 launches of the dominant kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-range", action="store_true", help="skip the second timed loop (bf16x6 everywhere)")
-    ap.add_argument("--cpu-utts", type=int, default=3)
+    ap.add_argument("--cpu-utts", type=int, default=5, help="CPU-baseline runs per configuration (median of)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --total-batch utterances over ALL ranks (BASELINE.json configs[4] as written: 256 over 8 "
+                         "GPUs) instead of --batch per rank")
+    ap.add_argument("--total-batch", type=int, default=256)
     args = ap.parse_args()
 
     import torch
@@ -180,6 +218,9 @@ def main():
     from jyutvoice_amd import engine, synth
     from jyutvoice_amd.runtime import get_runtime
 
+    if args.strong:      # this rank's contiguous share of the fixed global batch
+        lo_s, hi_s = jdist.shard_range(args.total_batch, rank, world)
+        args.batch = hi_s - lo_s
     B, Tt, n_steps = args.batch, args.tokens, args.timesteps
     T = 2 * Tt
     tts, hift = jyutvoice_amd.build_default(device)
@@ -187,7 +228,7 @@ def main():
     tts.load_state_dict(synth.tts_state_dict(fixed_duration=1.5))     # every token -> ceil(1.5) = 2 frames
     hift.load_state_dict(synth.hift_state_dict())
     hift.manual_seed(1234 + rank)
-    lo, _ = jdist.shard_range(B * world, rank, world)
+    lo, _ = jdist.shard_range(args.total_batch if args.strong else B * world, rank, world)
     batch = {k: v.to(device) for k, v in synth.batch(B, Tt, first_index=lo).items()}
 
     if args.workload == "c2":     # mu ~ N(0,1) [B,80,T], spks ~ N(0,1), cond = 0, full mask
@@ -261,28 +302,71 @@ def main():
         rt_eng = get_runtime(device).ensure(B, T, Tt)
         rt_eng.set_exact_range(True)
         step()
-        elapsed_exact, (res_x, _) = timed_loop(args.steps)
+        if profile:      # the same conditions as `value`: the first timed step carries the per-launch events (discarded here)
+            torch.cuda.synchronize(device)
+            engine.profile_enable(True)
+        elapsed_exact, (res_x, _) = timed_loop(args.steps, prof_steps)
+        if profile:
+            engine.profile_enable(False)
+            engine.profile_report()
         assert torch.isfinite(res_x["mel"]).all()
         rt_eng.set_exact_range(False)
 
+    # per-stage GPU time (encoder + duration predictor + length regulation | CFM loop | HiFT): three more passes, outside the
+    # timed region, with events on the launch stream at the stage boundaries; median
+    stage_ms = None
+    if args.workload == "c3" and rank == 0:
+        import statistics
+        runs = []
+        for _ in range(3):
+            tts.stage_events = []
+            step_res, _ = step()
+            e_end = torch.cuda.Event(enable_timing=True)
+            e_end.record(torch.cuda.current_stream(device))
+            torch.cuda.synchronize(device)
+            e0, e1, e2 = tts.stage_events
+            runs.append((e0.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e_end)))
+        tts.stage_events = None
+        med = [statistics.median(r[i] for r in runs) for i in range(3)]
+        stage_ms = {"encoder_dp_length_regulation": round(med[0], 3), "cfm_loop": round(med[1], 3), "hift": round(med[2], 3),
+                    "sum": round(sum(med), 3),
+                    "measured": "events on the launch stream at the stage boundaries, 3 passes outside the timed region, median"}
+
     if rank == 0:
-        frames = world * B * T * args.steps
+        frames = (args.total_batch if args.strong else world * B) * T * args.steps
         out = {
             "metric": "mel_frames_per_sec", "value": round(frames / elapsed, 1), "unit": "mel-frames/s",
             "rtf": round(elapsed / (frames * 0.02), 6), "x_realtime": round(frames * 0.02 / elapsed, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": ("f32 (bf16x6 split: 24-bit operands on the bf16 matrix cores, fp32 accumulate)" if os.environ.get("JV_EXACT_RANGE") else
                       "f32 (fp16x3 split: 22-bit operands on the fp16 matrix cores where a bound exists, bf16x6 = 24-bit elsewhere; fp32 accumulate)"),
             "data": "synthetic",
             "config": {"workload": ("C3: text encoder -> CFM flow decoder (Euler+CFG) -> HiFT vocoder, full synthesise()+inference()"
                                     if args.workload == "c3" else "C2: CFM flow decoder loop alone (Euler+CFG), N(0,1) mu, full mask"),
-                       "utterances_per_gpu": B, "global_batch": B * world, "tokens": Tt, "mel_frames": T,
+                       "utterances_per_gpu": B, "global_batch": args.total_batch if args.strong else B * world, "tokens": Tt, "mel_frames": T,
                        "audio_seconds_per_utterance": T * 0.02, "n_timesteps": n_steps, "parallelism": f"utterance-dp{world}",
                        "contraction": ("bf16x6 everywhere (JV_EXACT_RANGE)" if os.environ.get("JV_EXACT_RANGE") else
                                        "fp32-accurate split-plane MFMA: fp16x3 on the estimator's range-proven linears and "
                                        "attention, bf16x6 elsewhere (DESIGN.md 5; JV_EXACT_RANGE=1 forces bf16x6)")},
         }
+        if stage_ms:
+            out["stage_ms"] = stage_ms
+        groups = {k[len("_group:"):]: kern.pop(k) for k in [k for k in kern if k.startswith("_group:")]}
+        cs = groups.get("flow_conv_stack")
+        if cs and cs["ms"] > 0:
+            # BASELINE.json's north star asks for the HBM fraction of the flow decoder's Conv1d stack.  Algorithmic bytes as
+            # SURVEY.md 8(d) defines them: 96 064 B per CFG-sample-frame (each conv reads its input once and writes its output
+            # once, elementwise fused = 0) + 29.5 MB of weights per estimator call; time = HIP events over every launch of the
+            # stack (resnets, down / up / final convolutions, final projection, their LayerNorm passes) in the profiled step.
+            calls = n_steps * prof_steps
+            cs_bytes = calls * (96064.0 * 2 * B * T + 29.5e6)
+            gbs = cs_bytes / (cs["ms"] * 1e-3) / 1e9
+            out["conv_stack"] = {"bound": "hbm (as the north star prices it; the kernels themselves are matrix-pipe bound, DESIGN.md 5)",
+                                 "alg_bytes_per_pass": round(cs_bytes / prof_steps), "ms_per_pass": round(cs["ms"] / prof_steps, 3),
+                                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                 "launches_per_pass": cs["launches"] // prof_steps,
+                                 "alg_tflops": round(cs["flops"] / (cs["ms"] * 1e-3) / 1e12, 2)}
         if kern:
             tot_ms = sum(v["ms"] for v in kern.values())
             name, d = max(((k, v) for k, v in kern.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
@@ -320,13 +404,20 @@ def main():
         if elapsed_exact is not None:
             out["value_exact_range"] = round(frames / elapsed_exact, 1)
             out["ms_per_step_exact_range"] = round(1e3 * elapsed_exact / args.steps, 3)
-            out["exact_range_note"] = ("the same timed loop with every contraction on bf16x6 (24-bit operands, "
-                                       "jv_flow_set_contraction(1)); `value` is the default fp16x3 mode")
+            out["exact_range_note"] = ("the same timed loop, under the same conditions (first step instrumented), with every "
+                                       "contraction on bf16x6 (24-bit operands, jv_flow_set_contraction(1)); `value` is the default fp16x3 mode")
+        parity_ok = True
         if world == 1 and not args.no_cpu_baseline and args.workload == "c3":
             out["cpu_baseline"], parity = cpu_baseline(Tt, n_steps, args.cpu_utts, hip_out)
             if parity:
                 out["parity"] = parity
+                parity_ok = parity["ok"]
         print(json.dumps(out), flush=True)
+        if not parity_ok:      # a throughput measured on results outside the tolerance is not a result
+            sys.stderr.write("bench.py: parity against the CPU oracle is outside the tolerance -- see `parity` on the JSON line\n")
+            if use_dist:
+                dist.destroy_process_group()
+            sys.exit(3)
     if use_dist:
         dist.destroy_process_group()
 

@@ -47,6 +47,10 @@ void jv_destroy(jv_context* ctx);
  * pre-size once with the largest (batch, frames, tokens) a service expects rather than growing call by call.  The
  * reference has no counterpart: its nn.Modules allocate activations per call (infer.py:419-433). */
 int jv_reserve(jv_context* ctx, int max_batch, int max_frames, int max_tokens);
+/* jv_reserve is failure-atomic: when the new workspace does not fit, the previous capacities are restored and the error is
+ * returned; only if that fails as well is the context marked unusable -- jv_usable() then returns 0 and every other entry
+ * point JV_ERR_STATE until jv_destroy.  (1 otherwise; 0 for a null context.) */
+int jv_usable(const jv_context* ctx);
 /* message of the last failing call on this thread (valid until the next failure) */
 const char* jv_last_error(void);
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     "jv_create": (_i, [C.POINTER(_p), _i, _i, _i, _i]),
     "jv_destroy": (None, [_p]),
     "jv_reserve": (_i, [_p, _i, _i, _i]),
+    "jv_usable": (_i, [_p]),
     "jv_last_error": (C.c_char_p, []),
     "jv_num_tensors": (_i, [_p]),
     "jv_tensor_name": (C.c_char_p, [_p, _i]),

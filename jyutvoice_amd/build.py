@@ -27,6 +27,19 @@ if os.environ.get("JV_TUNING"):      # ablation switches + in-kernel stamps (too
     FLAGS.append("-DJV_TUNING")
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/*.h; names and contents), first 16 hex digits: what a
+    PMC traffic file under profiles/ is valid for (tools/profile_summary.py stores it, bench.py compares it)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) +
+                   glob.glob(os.path.join(HERE, "..", "include", "*.h")), key=os.path.basename)
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

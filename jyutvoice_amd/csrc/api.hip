@@ -51,6 +51,7 @@ using jv::Context;
 
 #define CTX_GUARD(ctx)                                                       \
   if (!(ctx)) return jv::fail(JV_ERR_ARG, "null context");                   \
+  if ((ctx)->c.broken) return jv::fail(JV_ERR_STATE, "context unusable: a workspace allocation failed and the previous capacities could not be restored (jv_reserve); destroy it"); \
   {                                                                          \
     hipError_t _e = hipSetDevice((ctx)->c.device);                           \
     if (_e != hipSuccess) return jv::fail(JV_ERR_HIP, hipGetErrorString(_e)); \
@@ -102,6 +103,7 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   c.no_splitk = getenv("JV_NO_SPLITK") != nullptr;
   c.rg_ff1 = getenv("JV_TILE_FF1") == nullptr;
   c.no_ffn_fuse = getenv("JV_NO_FFN_FUSE") != nullptr;
+  c.no_block_fuse = getenv("JV_NO_BLOCK_FUSE") != nullptr;
   c.no_attn_planes = getenv("JV_NO_ATTN_PLANES") != nullptr;
   c.max_frames = max_frames;
   c.max_tokens = max_tokens;
@@ -125,12 +127,30 @@ int jv_reserve(jv_context* ctx, int max_batch, int max_frames, int max_tokens) {
   if (max_batch < 1 || max_frames < 1 || max_tokens < 1) return jv::fail(JV_ERR_ARG, "jv_reserve: capacities must be >= 1");
   if (max_batch == c.max_batch && max_frames == c.max_frames && max_tokens == c.max_tokens) return JV_OK;
   JV_HIP(hipDeviceSynchronize());      // nothing queued may still use the old workspace (or replay a graph that points into it)
+  const int old_b = c.max_batch, old_f = c.max_frames, old_t = c.max_tokens;
   workspaces_destroy(c);
   c.max_batch = max_batch;
   c.max_frames = max_frames;
   c.max_tokens = max_tokens;
-  return workspaces_create(c);
+  int rc = workspaces_create(c);
+  if (rc == JV_OK) return JV_OK;
+  // Failure-atomic: a create that stopped part-way leaves workspace structs with null buffers behind.  Drop them and
+  // come back at the capacities the caller had (they fitted before); if even that fails the context refuses every call.
+  const std::string why = jv::g_last_error;
+  (void)hipGetLastError();
+  workspaces_destroy(c);
+  c.max_batch = old_b;
+  c.max_frames = old_f;
+  c.max_tokens = old_t;
+  if (workspaces_create(c) != JV_OK) {
+    workspaces_destroy(c);
+    c.broken = true;
+    return jv::fail(rc, "jv_reserve: " + why + " -- and the previous capacities could not be restored: context unusable");
+  }
+  return jv::fail(rc, "jv_reserve: " + why + " (capacities unchanged)");
 }
+
+int jv_usable(const jv_context* ctx) { return ctx && !ctx->c.broken ? 1 : 0; }
 
 void jv_destroy(jv_context* ctx) {
   if (!ctx) return;

@@ -376,6 +376,9 @@ int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
   }
   if (const char* ab = tuning_env("JV_ABLATE")) const_cast<ConvGemmArgs&>(a).ablate = atoi(ab);
   if ((a.W3 || a.W2) && nbatch == 1 && (a.ldw & 7) == 0 && !dyn_env("JV_NO_X6")) return conv_gemm_x6(a, st);
+  // only the split-plane kernels honour ksplit / grid.y: here the whole sum would land in partial[0] and the reduction
+  // would add stale partials to it
+  if (a.ksplit > 1) return fail(JV_ERR_ARG, "conv_gemm: split-K exists on the split-plane (x6 / h3) kernels only");
   if (a.A2 || a.out2) return fail(JV_ERR_ARG, "conv_gemm: fp16 plane operands exist on the fp16x3 path only");
   // Tile choice: the kernel is MFMA-bound, so cost ~ (#workgroup waves over 256 CUs) x tile area, with a mild penalty
   // for the smaller tiles' lower operand reuse; a variant must fit two workgroups' double-buffered LDS on a CU.

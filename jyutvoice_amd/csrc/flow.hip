@@ -13,6 +13,7 @@
 
 #include "jv_model.h"
 #include "jv_ops.h"
+#include "rowblock_kernel.h"
 #include "rowconv_kernel.h"
 
 namespace jv {
@@ -20,6 +21,7 @@ namespace jv {
 int rowgemm(const RowGemmArgs& a, int epi, hipStream_t st);   // rowgemm.hip
 int rowconv(const RowConvArgs& a, hipStream_t st);
 int rowffn(const RowFfnArgs& a, hipStream_t st);
+int rowblock(const RowBlockArgs& a, bool qkv, hipStream_t st);   // rowblock.hip
 int rowgemm_tile(int M);
 
 constexpr int FLOW_G = 4;      // leading guard rows (>= causal left context 2)
@@ -66,6 +68,8 @@ int flow_ws_create(Context& c) {
   FlowWs* w = new FlowWs();
   c.flow = w;
   const int B2 = 2 * c.max_batch;
+  // row indices are ints inside the kernels
+  if (c.max_batch > (1 << 20) || flow_rows(B2, c.max_frames) > (1L << 30)) return fail(JV_ERR_SHAPE, "flow workspace: batch x frames beyond 2^30 rows");
   w->rows_alloc = round_up((int)flow_rows(B2, c.max_frames), 128) + 256;
   const size_t R = (size_t)w->rows_alloc;
   auto F = [&](float** p, size_t floats) { return ws_alloc(c, floats * sizeof(float), reinterpret_cast<void**>(p)); };
@@ -207,6 +211,9 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   // grouping of a row's partial sums must not depend on how many rows the batch has, or a shard would no longer reproduce
   // the whole batch bit for bit (tests/test_gpu_dist.py).
   const int ksplit = (!c.no_splitk && g.M <= PARTIAL_ROWS) ? PARTIAL_SPLITS : 1;
+  // split-K lives in the split-plane kernels (conv_gemm_x6); a launch that would take the fp32-MFMA route (no weight
+  // planes, unaligned ldw, JV_NO_X6) runs unsplit instead
+  auto splittable = [&](const ConvGemmArgs& a) { return ksplit > 1 && (a.W3 || a.W2) && (a.ldw & 7) == 0 && !dyn_env("JV_NO_X6"); };
   // `a`: the full-semantics launch (N = 256); ln2 / out2: optional LayerNorm of the stored row for the next GEMM
   auto splitk = [&](const ConvGemmArgs& a, const LnW* ln2, float* out2) -> int {
     ConvGemmArgs p = a;
@@ -228,7 +235,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   // embedding / residual in its epilogue, no ln_epilogue_rows pass) when the batch fills the chip, else on the tile kernels
   const bool use_rc = !c.exact_range && !c.no_rowgemm && rowgemm_tile((int)g.M) > 0;
   auto conv3 = [&](ConvGemmArgs& a, const GemmW& m) -> int {
-    if (ksplit > 1 && a.N == 256 && !a.res2 && (m.w3 || m.w2)) return splitk(a, nullptr, nullptr);
+    if (splittable(a) && a.N == 256 && !a.res2) return splitk(a, nullptr, nullptr);
     if (!use_rc || !a.amax_in || !m.w2 || a.ntaps != 3 || a.tap_row0 != -2 || a.N != 256 || a.ldo != 256 && a.ldo != 512)
       return conv_gemm(a, 1, st);
     RowConvArgs r{};
@@ -244,7 +251,15 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     return rowconv(r, st);
   };
   // CausalResnetBlock1D (decoder.py:110-115, 784-795)
+  // (profiler: the estimator's Conv1d stack -- resnets, down / up / final convolutions, final projection -- is summed as one
+  // group; BASELINE.json's north star quotes an HBM fraction for it)
+  struct ConvStackScope {
+    bool on;
+    ConvStackScope() : on(prof_on()) { if (on) prof_group("flow_conv_stack"); }
+    ~ConvStackScope() { if (on) prof_group(nullptr); }
+  };
   auto resnet = [&](int i, const float* in, int ldin, float* out, int ldo) -> int {
+    ConvStackScope scope;
     const ResnetW& r = e.res[i];
     ConvGemmArgs a = base_args(g, in, ldin, r.block1, w.h2, 256);
     causal3(a);
@@ -283,8 +298,16 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     if (pre(m)) return layernorm256_planes(h, reinterpret_cast<unsigned short*>(w.ln), R * 256, m.a_scale, n.g, n.b, 1e-5f, g.M, st);
     return layernorm_rows(h, nullptr, w.ln, n.g, n.b, 1e-5f, g.M, 256, nullptr, st);
   };
+  // one decision for every block of the call (a block's split-K tail writes the NEXT block's LayerNorm): all of them take
+  // the split-plane route, or none is split
+  bool sk_blocks = ksplit > 1 && !c.dma_a && !dyn_env("JV_NO_X6");
+  for (int i = 0; i < EST_NRES && sk_blocks; ++i)
+    for (int j = 0; j < EST_NBLK; ++j) {
+      const GemmW &o = e.blk[i][j].out, &f = e.blk[i][j].ff2;
+      sk_blocks = sk_blocks && (o.w3 || o.w2) && (f.w3 || f.w2) && !(o.ldw & 7) && !(f.ldw & 7);
+    }
   auto btb = [&](const BtbW& b, const BtbW* next, bool ln_ready, float* h, float* out, int ldo) -> int {
-    const bool sk = ksplit > 1 && !c.dma_a;      // split-K tails also write the next LayerNorm (fp32 rows) into w.ln
+    const bool sk = sk_blocks;      // split-K tails also write the next LayerNorm (fp32 rows) into w.ln
     if (!(sk && ln_ready)) JV_TRY(ln_to(b.n1, b.qkv, h));
     ConvGemmArgs a = base_args(g, w.ln, 256, b.qkv, w.qkv, 1536);
     h3(a, b.qkv);
@@ -348,8 +371,15 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   auto rg_track = [&](RowGemmArgs& a) {
     a.amax_out = slots_of(a.out); a.row_slot = w.row_sample; a.row_mask = w.rowmask;
   };
-  auto btb_rg = [&](const BtbW& b, const BtbW* next, bool ln_ready, float* h, float* out, int ldo) -> int {
-    if (!ln_ready) JV_TRY(layernorm256_planes(h, reinterpret_cast<unsigned short*>(w.ln), R * 256, b.qkv.a_scale, b.n1.g, b.n1.b, 1e-5f, g.M, st));
+  // `qkv_ready`: the previous block's fused launch has already produced this block's q | k | v (rowblock_kernel.h);
+  // `qkv_next` (out): this block's launch produced the next block's
+  auto ffn_fusable = [&](const BtbW& b) {
+    return c.rg_ff1 && !c.no_ffn_fuse && b.ff1.wf && b.ff2.wf && b.ff1.N == 1024 && b.ff1.Cin == 256 && b.ff2.N == 256 && b.ff2.Cin == 1024;
+  };
+  auto btb_rg = [&](const BtbW& b, const BtbW* next, bool ln_ready, bool qkv_ready, bool* qkv_next, float* h, float* out, int ldo) -> int {
+    *qkv_next = false;
+    if (!ln_ready && !qkv_ready)
+      JV_TRY(layernorm256_planes(h, reinterpret_cast<unsigned short*>(w.ln), R * 256, b.qkv.a_scale, b.n1.g, b.n1.b, 1e-5f, g.M, st));
     // q | k | v = to_q/k/v(ln): q as fp32 rows [R,512] at the head of the qkv buffer, k and v as fp16 planes [2][R][1024]
     // behind it (same bytes as [R,1536] fp32), scaled for the attention kernel, which then splits nothing
     RowGemmArgs a = rg_args(w.ln, 256, b.qkv);
@@ -361,9 +391,11 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     at.q_scale = b.q_scale; at.k_scale = b.k_scale; at.v_scale = b.v_scale;
     at.out2 = reinterpret_cast<unsigned short*>(w.att); at.out2_plane = R * 512; at.out2_scale = b.out.a_scale;
     if (!c.no_attn_planes) {
-      a.out = w.qkv; a.ldo = 512;
-      a.out2 = kv2; a.out2_plane = R * 1024; a.ldo2 = 1024; a.out2_scale = b.k_scale; a.out2_scale2 = b.v_scale;
-      JV_TRY(rowgemm(a, RG_QKV, st));
+      if (!qkv_ready) {
+        a.out = w.qkv; a.ldo = 512;
+        a.out2 = kv2; a.out2_plane = R * 1024; a.ldo2 = 1024; a.out2_scale = b.k_scale; a.out2_scale2 = b.v_scale;
+        JV_TRY(rowgemm(a, RG_QKV, st));
+      }
       at.ld = 512; at.kv2 = kv2; at.kv2_plane = R * 1024; at.kv_ld = 1024;
       JV_TRY(attention64_planes(at, st));
     } else {
@@ -372,13 +404,36 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
       at.ld = 1536; at.k_off = 512; at.v_off = 1024;
       JV_TRY(attention64(at, st));
     }
+    if (!c.no_block_fuse && !c.no_attn_planes && ffn_fusable(b) && b.out.wf && b.out.N == 256 && b.out.Cin == 512 &&
+        (!next || (next->qkv.wf && next->qkv.N == 1536 && next->qkv.Cin == 256 && !next->qkv.bias))) {
+      // to_out -> LayerNorm3 -> feed-forward (-> the next block's LayerNorm1 -> q | k | v) in ONE launch on the same rows: the
+      // LayerNorm planes never leave LDS (rowblock_kernel.h)
+      RowBlockArgs f{};
+      f.A2 = reinterpret_cast<const unsigned short*>(w.att); f.a2_plane = R * 512; f.a_rows = g.a_rows; f.lda2 = 512; f.M = (int)g.M;
+      f.Wof = b.out.wf; f.wof_plane = (long)b.out.N * b.out.Cin; f.cso = b.out.colscale; f.bo = b.out.bias; f.a_scale_o = b.out.a_scale;
+      f.h = h; f.ldh = 256; f.ln3_g = b.n3.g; f.ln3_b = b.n3.b; f.ln_eps = 1e-5f;
+      f.W1f = b.ff1.wf; f.w1f_plane = (long)b.ff1.N * b.ff1.Cin; f.cs1 = b.ff1.colscale; f.b1 = b.ff1.bias; f.a_scale1 = b.ff1.a_scale;
+      f.h_scale = b.ff2.a_scale;
+      f.W2f = b.ff2.wf; f.w2f_plane = (long)b.ff2.N * b.ff2.Cin; f.cs2 = b.ff2.colscale; f.b2 = b.ff2.bias;
+      f.out = out; f.ldo = ldo;
+      f.amax_h = slots_of(h); f.amax_out = slots_of(out); f.row_slot = w.row_sample; f.row_mask = w.rowmask;
+      f.alg_rows = (long)g.B2 * g.T;
+      const bool qkv = next && out == h;
+      if (qkv) {
+        f.ln1_g = next->n1.g; f.ln1_b = next->n1.b;
+        f.Wqf = next->qkv.wf; f.wqf_plane = (long)next->qkv.N * next->qkv.Cin; f.csq = next->qkv.colscale; f.a_scale_q = next->qkv.a_scale;
+        f.q = w.qkv; f.ldq = 512; f.kv2 = kv2; f.kv2_plane = R * 1024; f.ldkv = 1024; f.k_scale = next->k_scale; f.v_scale = next->v_scale;
+      }
+      *qkv_next = qkv;
+      return rowblock(f, qkv, st);
+    }
     a = rg_args(w.att, 512, b.out);      // h += to_out(att); ln = LayerNorm3(h)
     a.out = h; a.ldo = 256; a.res = h; a.ldr = 256;
     a.out2 = reinterpret_cast<unsigned short*>(w.ln); a.out2_plane = R * 256; a.ldo2 = 256; a.out2_scale = b.ff1.a_scale;
     a.ln_g = b.n3.g; a.ln_b = b.n3.b;
     rg_track(a);
     JV_TRY(rowgemm(a, RG_RES_LN, st));
-    if (c.rg_ff1 && !c.no_ffn_fuse && b.ff1.wf && b.ff2.wf && b.ff1.N == 1024 && b.ff1.Cin == 256 && b.ff2.N == 256 && b.ff2.Cin == 1024) {
+    if (ffn_fusable(b)) {
       // the feed-forward pair in one launch (rowffn_kernel): the 1024-wide hidden tile never leaves LDS
       RowFfnArgs f{};
       f.A2 = reinterpret_cast<const unsigned short*>(w.ln); f.a2_plane = R * 256; f.a_rows = g.a_rows; f.lda2 = 256; f.M = (int)g.M;
@@ -424,9 +479,10 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   auto stage_blocks = [&](const BtbW* blk, float* h, float* last_out, int last_ldo) -> int {
     bool all = use_rg;
     for (int j = 0; j < EST_NBLK; ++j) all = all && rg_ok(blk[j]);
+    bool qkv_ready = false;
     for (int j = 0; j < EST_NBLK; ++j) {
       const bool last = j == EST_NBLK - 1;
-      if (all) JV_TRY(btb_rg(blk[j], last ? nullptr : &blk[j + 1], j > 0, h, last ? last_out : h, last ? last_ldo : 256));
+      if (all) JV_TRY(btb_rg(blk[j], last ? nullptr : &blk[j + 1], j > 0, qkv_ready, &qkv_ready, h, last ? last_out : h, last ? last_ldo : 256));
       else JV_TRY(btb(blk[j], last ? nullptr : &blk[j + 1], j > 0, h, last ? last_out : h, last ? last_ldo : 256));
     }
     return JV_OK;
@@ -436,6 +492,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   JV_TRY(resnet(0, w.xin, 320, w.h, 256));
   JV_TRY(stage_blocks(e.blk[0], w.h, skip, 512));
   {
+    ConvStackScope scope;
     ConvGemmArgs a = base_args(g, skip, 512, e.down_conv, w.h, 256);
     causal3(a);
     h3m(a, e.down_conv);
@@ -451,6 +508,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   JV_TRY(resnet(EST_NRES - 1, w.cat, 512, w.h, 256));
   JV_TRY(stage_blocks(e.blk[EST_NRES - 1], w.h, w.h, 256));
   {
+    ConvStackScope scope;
     ConvGemmArgs a = base_args(g, w.h, 256, e.up_conv, w.h2, 256);
     causal3(a);
     h3m(a, e.up_conv);

@@ -170,6 +170,7 @@ int conv_gemm_x6(const ConvGemmArgs& a, hipStream_t st);   // split-plane main l
 bool prof_on();
 void prof_begin(hipStream_t st);                                   // records the start event
 void prof_end(hipStream_t st, const char* name, double flops, double bytes);   // records the stop event
+void prof_group(const char* tag);   // launches until the next call also count under "_group:<tag>" (null: none)
 
 // ---- attention (attention.hip) -----------------------------------------------------------------
 struct AttnArgs {

@@ -122,6 +122,7 @@ struct Context {
   std::unordered_map<std::string, int> index;
   Arena raw_arena, packed;
   bool ready[3] = {false, false, false};
+  bool broken = false;           // jv_reserve failed and could not restore the old workspace: every entry point returns JV_ERR_STATE
   EstimatorW est;
   EncoderW enc;
   HiftW hift;
@@ -131,6 +132,7 @@ struct Context {
   bool dma_a = false;            // JV_DMA_A=1: fp16x3 linears take their A operand pre-split from the producer (measured slower
                                  // in the pipeline than the in-kernel split; kept as a tested alternative)
   bool no_ffn_fuse = false;      // JV_NO_FFN_FUSE=1: ff.net.0 and ff.net.2 as two launches (the path rowffn_kernel is checked against)
+  bool no_block_fuse = false;    // JV_NO_BLOCK_FUSE=1: to_out / feed-forward / next q|k|v as three launches (the path rowblock_kernel is checked against)
   bool rg_ff1 = true;            // ff.net.0 on the row-owning GEMM too; JV_TILE_FF1=1: on the tile kernel (the round-2 first build, for A/B runs)
   bool no_attn_planes = false;   // JV_NO_ATTN_PLANES=1: attention splits K / V itself (attention.hip) instead of taking planes
   bool no_splitk = false;        // JV_NO_SPLITK=1: no split-K at short M (A/B aid)

@@ -16,6 +16,7 @@ namespace {
 struct Span {
   hipEvent_t a, b;
   const char* name;
+  const char* group;      // null, or a stage tag set by the caller around a run of launches (prof_group)
   double flops, bytes;
 };
 struct Prof {
@@ -23,6 +24,7 @@ struct Prof {
   std::vector<Span> spans;
   std::vector<hipEvent_t> pool;
   hipEvent_t pending = nullptr;
+  const char* group = nullptr;
   std::mutex mu;
 };
 Prof g_prof;
@@ -41,6 +43,12 @@ hipEvent_t get_event() {
 
 bool prof_on() { return g_prof.on; }
 
+// launches recorded until the next call are also summed under "_group:<tag>" in the report (tag: a string literal; null: none)
+void prof_group(const char* tag) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.group = tag;
+}
+
 void prof_begin(hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
   g_prof.pending = get_event();
@@ -51,7 +59,7 @@ void prof_end(hipStream_t st, const char* name, double flops, double bytes) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
   hipEvent_t b = get_event();
   (void)hipEventRecord(b, st);
-  g_prof.spans.push_back(Span{g_prof.pending, b, name, flops, bytes});
+  g_prof.spans.push_back(Span{g_prof.pending, b, name, g_prof.group, flops, bytes});
   g_prof.pending = nullptr;
 }
 
@@ -77,6 +85,10 @@ int jv_profile_report(char* json, int64_t cap) {
     if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) ms = 0.f;
     Agg& a = agg[s.name];
     a.n += 1; a.ms += ms; a.flops += s.flops; a.bytes += s.bytes;
+    if (s.group) {
+      Agg& gsum = agg[std::string("_group:") + s.group];
+      gsum.n += 1; gsum.ms += ms; gsum.flops += s.flops; gsum.bytes += s.bytes;
+    }
     g_prof.pool.push_back(s.a);
     g_prof.pool.push_back(s.b);
   }

@@ -1,0 +1,64 @@
+// Host side of the fused transformer-block launch (rowblock_kernel.h): argument checks, tile height, launch.
+#include "rowblock_kernel.h"
+
+namespace jv {
+
+int rowgemm_tile(int M);      // rowgemm.hip
+
+namespace {
+template <int RT, bool QKV>
+int rb_launch(const RowBlockArgs& a, hipStream_t st) {
+  static bool raised[64] = {};
+  int dev = 0;
+  JV_HIP(hipGetDevice(&dev));
+  if (!raised[dev & 63]) {
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowblock_kernel<RT, QKV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               rb_lds_bytes<RT>()));
+    raised[dev & 63] = true;
+  }
+  const bool prof = prof_on();
+  if (prof) prof_begin(st);
+  hipLaunchKernelGGL((rowblock_kernel<RT, QKV>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rb_lds_bytes<RT>(), st, a);
+  if (prof) {
+    static const std::string name = std::string("rowblock_h3<") + std::to_string(16 * RT) + "x256" + (QKV ? ",qkv>" : ">");
+    const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M);
+    // algorithmic work: to_out (512 -> 256) + ff.net.0 (256 -> 1024) + ff.net.2 (1024 -> 256) (+ q|k|v: 256 -> 1536);
+    // bytes: attention planes in (512 x 4 B per row), residual in, rows out (256 x 4 B each), the weights, (+ q|k|v out)
+    const double macs = 256.0 * 512 + 2.0 * 256 * 1024 + (QKV ? 256.0 * 1536 : 0.0);
+    const double bytes = 4.0 * (rows * (512 + 256 + 256 + (QKV ? 1536 : 0)) + macs);
+    prof_end(st, name.c_str(), 2.0 * rows * macs, bytes);
+  }
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+
+template <int RT>
+int rb_launch1(const RowBlockArgs& a, bool qkv, hipStream_t st) {
+  return qkv ? rb_launch<RT, true>(a, st) : rb_launch<RT, false>(a, st);
+}
+}  // namespace
+
+// h += to_out(att); out = h + ff.net.2(gelu(ff.net.0(LayerNorm3(h)))); qkv: q | k | v = to_q/k/v_next(LayerNorm1_next(out))
+int rowblock(const RowBlockArgs& a, bool qkv, hipStream_t st) {
+  if (a.M <= 0) return JV_OK;
+  if (!a.A2 || !a.Wof || !a.cso || !(a.a_scale_o > 0.f) || !a.h || !a.ln3_g || !a.ln3_b)
+    return fail(JV_ERR_ARG, "rowblock: to_out needs the attention planes, fragment-order weights, scales, h and LayerNorm3");
+  if (!a.W1f || !a.W2f || !a.cs1 || !a.cs2 || !(a.a_scale1 > 0.f) || !(a.h_scale > 0.f) || !a.out)
+    return fail(JV_ERR_ARG, "rowblock: the feed-forward pair needs both weight matrices in fragment order, their scales and an output");
+  if ((a.lda2 & 7) || (a.ldh & 3) || (a.ldo & 3)) return fail(JV_ERR_ARG, "rowblock: aligned strides required");
+  if (qkv && (!a.Wqf || !a.csq || !(a.a_scale_q > 0.f) || !a.ln1_g || !a.ln1_b || !a.q || !a.kv2 || (a.ldq & 3) || (a.ldkv & 3) ||
+              !(a.k_scale > 0.f) || !(a.v_scale > 0.f)))
+    return fail(JV_ERR_ARG, "rowblock: the q|k|v phase needs LayerNorm1, fragment-order weights, scales, a q buffer and a K/V plane buffer");
+  int rt = rowgemm_tile(a.M);
+  if (rt == 0) rt = 2;
+  switch (rt) {
+    case 1:
+    case 2: return rb_launch1<2>(a, qkv, st);
+    case 3: return rb_launch1<3>(a, qkv, st);
+    case 4: return rb_launch1<4>(a, qkv, st);
+    case 5: return rb_launch1<5>(a, qkv, st);
+    default: return fail(JV_ERR_ARG, "rowblock: bad tile height");
+  }
+}
+
+}  // namespace jv

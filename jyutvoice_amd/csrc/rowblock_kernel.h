@@ -1,0 +1,590 @@
+// One row-owning launch for the tail of a BasicTransformerBlock and the head of the next one
+// (jyutvoice/flow/transformer.py:355-443): on the same 16 RT rows,
+//   phase A   h  += attn1.to_out.0(att) + bias                      (K = 512: the attention planes stream through a ring)
+//             x   = LayerNorm3(h)                                    -> fp16 planes, written INTO the resident operand image
+//   phase B   out = h + ff.net.2(gelu(ff.net.0(x)))                  (rowffn_kernel's loop: hidden tile in LDS)
+//             x'  = LayerNorm1_next(out)                             -> planes, into the operand image again          [QKV]
+//   phase C   q | k | v = to_q/k/v_next(x')                          (rowgemm_wa_kernel's loop, per-wave epilogues)    [QKV]
+// Unfused these are three launches (rowgemm_wd<res,ln>, rowffn, rowgemm_wa<qkv>) that own the same rows: each pays a launch
+// ramp and a tail, and the LayerNorm planes (20 MB at 19.5 K rows) travel to HBM and straight back twice per block.  Here
+// they never leave LDS.  What stays in HBM between the phases is the residual stream itself: phase A stores h and phase
+// B's epilogue reads the same values back (the same lane reads what it wrote) -- at 2 waves per SIMD a wave has 256
+// registers and the feed-forward loop uses 242 of them, so the 40 the rows would need do not exist.
+//
+// LDS (32 RT KB; 160 KB at RT = 5), in STAGE = 2 KB x RT units (one 32-deep k-step of the 16 RT rows as two fp16 planes):
+//   [0, 8)    X: the K = 256 operand image (LayerNorm planes), rowgemm_wa_kernel's layout
+//   [8, 16)   phase A: the 3-stage ring of the attention planes, then the epilogue slab; phase B: the hidden image H, then
+//             the epilogue slab; phase C: the eight per-wave transposition patches
+// The slab is the whole tile as fp32, UNPADDED (16 RT rows x 1 KB = 8 stages exactly): instead of rowgemm's 260-float rows
+// the 64-byte groups of a row are XOR-ed with bits 2..3 of the row, which keeps the MFMA-layout writes on 64 distinct banks
+// and the row pass's 16-byte reads aligned.
+//
+// The weight fragments of all four linears arrive through ONE register double buffer (rowgemm_wd_kernel explains the
+// hand-counted waits): the loader walks a sequence of 8-step segments -- Wo k 0..7, Wo k 8..15, then per hidden chunk
+// W1[chunk] and W2[k-steps of the chunk], then the six 256-column chunks of Wqkv -- two steps ahead of the MFMAs, and
+// wraps around to the first segment past the end (those loads land in registers nothing reads).
+// Arithmetic: every sum in the K order of the separate kernels, the same epilogue expressions -- bit-identical results
+// (tests/test_gpu_pipeline.py::test_fused_block_equals_separate_launches).
+#pragma once
+#include "rowgemm_kernel.h"
+
+namespace jv {
+
+struct RowBlockArgs {
+  // ---- phase A: attn1.to_out.0 (N = 256, K = 512) + residual + LayerNorm3
+  const unsigned short* A2;      // attention planes [2][a_rows][lda2] of att * a_scale_o
+  long a2_plane, a_rows;
+  int lda2, M;
+  const unsigned short* Wof;     // fragment order, plane stride wof_plane halves
+  long wof_plane;
+  const float *cso, *bo;
+  float a_scale_o;
+  float* h;                      // [rows, ldh] fp32: residual in, h + to_out(att) out (in place)
+  long ldh;
+  const float *ln3_g, *ln3_b;
+  float ln_eps;
+  // ---- phase B: ff.net.0 (N = 1024, K = 256) -> GELU -> ff.net.2 (N = 256, K = 1024) + residual
+  const unsigned short* W1f;
+  long w1f_plane;
+  const float *cs1, *b1;
+  float a_scale1, h_scale;       // a_scale1: what LayerNorm3's planes are scaled with; h_scale: the hidden planes
+  const unsigned short* W2f;
+  long w2f_plane;
+  const float *cs2, *b2;
+  float* out;                    // fp32 rows (h itself, or the skip / concat buffer for a stage's last block)
+  long ldo;
+  // measured-bound tracking of what phases A and B store (RowGemmArgs::amax_out)
+  float *amax_h, *amax_out;
+  const int* row_slot;
+  const unsigned char* row_mask;
+  // ---- phase C (QKV): the next block's norm1 and to_q | to_k | to_v (N = 1536, K = 256)
+  const float *ln1_g, *ln1_b;
+  const unsigned short* Wqf;
+  long wqf_plane;
+  const float* csq;
+  float a_scale_q;               // what LayerNorm1's planes are scaled with
+  float* q;                      // fp32 rows [., ldq], 512 columns
+  long ldq;
+  unsigned short* kv2;           // planes [2][rows][ldkv]: k * k_scale in columns 0..511, v * v_scale in 512..1023
+  long kv2_plane;
+  int ldkv;
+  float k_scale, v_scale;
+  long alg_rows;
+};
+
+template <int RT> constexpr int rb_lds_bytes() { return 16 * rgw_stage_bytes<RT>(); }
+
+// element (row, col) of the swizzled slab, in floats
+__device__ __forceinline__ int rb_slab(int row, int col) { return row * 256 + (col ^ (((row >> 2) & 3) << 4)); }
+
+template <int RT, bool QKV>
+__global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rg_lds[];
+  constexpr int R = 16 * RT;
+  constexpr int STAGE = rgw_stage_bytes<RT>();
+  constexpr int A_PLANE = R * 64;
+  constexpr int NPIECE = 2 * RT;                 // 1 KiB DMA pieces per ring stage
+  constexpr int PPW = (NPIECE + 7) / 8;
+  constexpr int NWL = 4;
+  constexpr int KSA = 16, KS = 8, NCH = 4, NCQ = 6;
+  constexpr int H_OFF = KS * STAGE;
+  constexpr int NSEG = QKV ? 2 + 2 * NCH + NCQ : 2 + 2 * NCH;
+  constexpr int NRW = 2 * RT;                    // rows per wave in the row passes
+  static_assert(8 * STAGE == R * 1024, "the unpadded slab is exactly the upper half of LDS");
+  static_assert(8 * 16 * 36 * 4 <= 8 * STAGE, "the per-wave patches of phase C fit there too");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * R;
+  const unsigned lane4 = 4u * (unsigned)lane;      // this lane's four columns in the row passes
+  unsigned char* const hreg = rg_lds + H_OFF;
+  float* const slab = reinterpret_cast<float*>(hreg);
+
+  // ---- L2 warm-up of the weights (rowgemm_kernel): the workgroups that share an XCD touch every 128-byte line of a matrix
+  // once.  Wo and W1 at kernel start; W2 while phase A's epilogue runs; Wqkv while phase B's does -- a matrix touched a
+  // hundred microseconds ahead would be gone from a 4 MB L2 by the time its phase starts.
+  const int wgrp = blockIdx.x >> 3, wngrp = (gridDim.x + 7) >> 3;
+  auto warm_lines = [&](const unsigned short* base, long plane_halves, long lines_per_plane, int round) -> float {
+    const long per = (2 * lines_per_plane + wngrp - 1) / wngrp;
+    const long i = tid + 512L * round;
+    const long l = (long)wgrp * per + i;
+    float v = 0.f;
+    if (i < per && l < 2 * lines_per_plane) {
+      const int pl = l >= lines_per_plane;
+      v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + (long)pl * plane_halves) + ((l - pl * lines_per_plane) << 7));
+    }
+    return v;
+  };
+  float warm = warm_lines(p.Wof, p.wof_plane, 2048, 0);      // 256 x 512 halves = 256 KB per plane
+  float warm1 = warm_lines(p.W1f, p.w1f_plane, 4096, 0);     // 1024 x 256 halves = 512 KB per plane
+
+  // ---- phase A operand: the attention planes through a 3-stage ring in the upper half (rowgemm_wd_kernel) ----
+  const unsigned short* cur[PPW];
+  int dst[PPW];
+  {
+    const int prow = lane >> 2, pslot = (lane & 3) ^ rg_key(prow);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave + 8 * i;
+      const int pl = pc / RT, g = pc % RT;
+      long row = (long)m0 + g * 16 + prow;
+      row = row < p.a_rows ? row : p.a_rows - 1;
+      cur[i] = p.A2 + (long)(pl & 1) * p.a2_plane + row * p.lda2 + 8 * pslot;
+      dst[i] = (pl & 1) * A_PLANE + g * 1024;
+    }
+  }
+  const int my_pieces = (NPIECE - wave + 7) / 8 > 0 ? (NPIECE - wave + 7) / 8 : 0;      // wave-uniform
+  auto issue_piece = [&](auto itag, int stage) {
+    constexpr int i = decltype(itag)::value;
+    if (wave + 8 * i < NPIECE) {      // wave-uniform
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)cur[i],
+                                       (__attribute__((address_space(3))) void*)(hreg + stage * STAGE + dst[i]), 16, 0, 0);
+    }
+  };
+  auto advance_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) cur[i] += 32;
+  };
+
+  // ---- W: the segment walker.  Fragment (nt, pl) of step j of a segment sits at
+  //   base + pl * plane + (((blk0 + 2 wave + nt) * KSm + k0 + j) * 64 + lane) * 8 halves
+  const unsigned short* wp[2][2];
+  int wseg = 0, wj = 0;
+  auto seg_ptrs = [&](const int seg) {      // wave-uniform
+    const unsigned short* base;
+    long plane;
+    int blk0, ksm, k0;
+    if (seg < 2) {
+      base = p.Wof; plane = p.wof_plane; blk0 = 0; ksm = KSA; k0 = 8 * seg;
+    } else if (seg < 2 + 2 * NCH) {
+      const int c = (seg - 2) >> 1;
+      if (((seg - 2) & 1) == 0) { base = p.W1f; plane = p.w1f_plane; blk0 = 16 * c; ksm = 8; k0 = 0; }
+      else { base = p.W2f; plane = p.w2f_plane; blk0 = 0; ksm = 32; k0 = 8 * c; }
+    } else {
+      base = p.Wqf; plane = p.wqf_plane; blk0 = 16 * (seg - 2 - 2 * NCH); ksm = 8; k0 = 0;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        wp[nt][pl] = base + (long)pl * plane + ((long)(blk0 + 2 * wave + nt) * ksm + k0) * 512 + lane * 8;
+  };
+  seg_ptrs(0);
+  rg_u32x4 bq[2][2][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bq[i >> 2][(i >> 1) & 1][i & 1] = rg_u32x4{0u, 0u, 0u, 0u};
+  auto load_frag = [](rg_u32x4& dst, const unsigned short* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(ptr) : "memory");
+  };
+  auto load_w = [&](auto par_tag, auto nttag) {
+    constexpr int par = decltype(par_tag)::value, nt = decltype(nttag)::value;
+    load_frag(bq[par][nt][0], wp[nt][0]);
+    load_frag(bq[par][nt][1], wp[nt][1]);
+  };
+  auto landed_w = [](rg_u32x4& b00, rg_u32x4& b01, rg_u32x4& b10, rg_u32x4& b11) {
+    asm volatile("" : "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11)::"memory");
+  };
+  auto advance_w = [&]() {
+    if (++wj == 8) {
+      wj = 0;
+      if (++wseg == NSEG) wseg = 0;      // past the end: wrap around to weights that exist
+      seg_ptrs(wseg);
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) wp[nt][pl] += 512;
+    }
+  };
+
+  const int fslot = (kq ^ rg_key(r16)) << 4;
+  const int a_off = r16 * 64 + fslot;
+  rg_u32x4 af[2][RT][2];
+  auto read_a = [&](auto par_tag, const unsigned char* st) {
+    constexpr int par = decltype(par_tag)::value;
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) af[par][mt][pl] = *reinterpret_cast<const rg_u32x4*>(st + a_off + pl * A_PLANE + mt * 1024);
+  };
+  auto mfma_block = [&](auto par_tag, auto nttag, rg_f32x4 (&acc)[RT][2], auto mt_tag) {
+    constexpr int par = decltype(par_tag)::value, nt = decltype(nttag)::value, mt = decltype(mt_tag)::value;
+    rg_f32x4 t = acc[mt][nt];
+    auto mm = [&](const rg_u32x4& x, const rg_u32x4& y) {
+      t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rg_f16x8, x), __builtin_bit_cast(rg_f16x8, y), t, 0, 0, 0);
+    };
+    mm(af[par][mt][1], bq[par][nt][0]);      // smallest terms first, as everywhere
+    mm(af[par][mt][0], bq[par][nt][1]);
+    mm(af[par][mt][0], bq[par][nt][0]);
+    acc[mt][nt] = t;
+  };
+
+  // ---- prologue: ring stages 0..2, W of steps 0 and 1; everything waited for once ----
+#pragma unroll
+  for (int st = 0; st < 3; ++st) {
+    issue_piece(std::integral_constant<int, 0>{}, st);
+    if constexpr (PPW > 1) issue_piece(std::integral_constant<int, 1>{}, st);
+    advance_a();
+    if (st < 2) {
+      if (st == 0) {
+        load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+      } else {
+        load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+      }
+      advance_w();
+    }
+  }
+  rg_wait_vmcnt<0>();
+  landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
+  landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
+  rg_barrier();
+  read_a(std::integral_constant<int, 0>{}, hreg);
+
+  rg_f32x4 acc1[RT][2], acc2[RT][2];
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ================================ phase A: acc1 = att Wo^T (16 steps through the ring) ================================
+  // rowgemm_wd_kernel's step.  This wave's memory operations in program order:
+  //   ... W0(s+1), A(s+2), W1(s+1) | W0(s+2), <wait of step s>, A(s+3), W1(s+2) | ...
+  // needed at the wait: A(s+1), W0(s+1), W1(s); behind W0(s+1): A(s+2) (if it exists), W1(s+1), W0(s+2).  The ring is NOT fed
+  // past the end of the phase (its stages become the slab), so the last two steps count the W loads alone.
+  {
+    int s = 0, s3 = 0;
+    auto stepA = [&](auto par_tag) {
+      constexpr int par = decltype(par_tag)::value;
+      const bool more_a = s + 3 < KSA;
+      auto group = [&](auto mtag, auto nttag) {
+        constexpr int mt = decltype(mtag)::value, nt = decltype(nttag)::value;
+        mfma_block(par_tag, nttag, acc1, mtag);
+        if constexpr (nt == 1 && mt < PPW) {
+          if (more_a) issue_piece(std::integral_constant<int, (mt < PPW ? mt : 0)>{}, s3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto block = [&](auto nttag) {
+        group(std::integral_constant<int, 0>{}, nttag);
+        if constexpr (RT > 1) group(std::integral_constant<int, 1>{}, nttag);
+        if constexpr (RT > 2) group(std::integral_constant<int, 2>{}, nttag);
+        if constexpr (RT > 3) group(std::integral_constant<int, 3>{}, nttag);
+        if constexpr (RT > 4) group(std::integral_constant<int, 4>{}, nttag);
+        load_w(par_tag, nttag);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      block(std::integral_constant<int, 0>{});
+      if (s + 2 < KSA) {
+        if (my_pieces == PPW) rg_wait_vmcnt<NWL + PPW>();
+        else rg_wait_vmcnt<NWL + PPW - 1>();
+      } else {
+        rg_wait_vmcnt<NWL>();
+      }
+      landed_w(bq[par][1][0], bq[par][1][1], bq[par ^ 1][0][0], bq[par ^ 1][0][1]);
+      rg_barrier();
+      const int s3n = s3 == 2 ? 0 : s3 + 1;
+      if (s + 1 < KSA) read_a(std::integral_constant<int, par ^ 1>{}, hreg + s3n * STAGE);
+      __builtin_amdgcn_sched_barrier(0);
+      block(std::integral_constant<int, 1>{});
+      if (more_a) advance_a();
+      advance_w();
+      ++s;
+      s3 = s3n;
+    };
+#pragma unroll 1
+    for (int ks = 0; ks < KSA; ks += 2) {
+      stepA(std::integral_constant<int, 0>{});
+      stepA(std::integral_constant<int, 1>{});
+    }
+  }
+  // what the first step of phase B waits for in its middle -- W0(17), W1(16) -- has only W1(17) behind it so far; counted
+  // HERE, ahead of the epilogue's own loads and stores (vmcnt retires in order: counting behind them would wait for them)
+  rg_wait_vmcnt<2>();
+
+  // Per-row facts of the tracking (mask, slot, the slot's current maximum): lane j < NRW loads those of the wave's row j --
+  // three vector loads per epilogue, the last dependent on the second -- and the row pass broadcasts them with v_readlane.
+  // (Asked for row by row they are wave-uniform values: the compiler turned them into 2 NRW scalar-path loads, each behind
+  // its own branch and s_waitcnt vmcnt(0) -- a serial chain of twenty L2 round trips per epilogue.)
+  struct RowFacts { int slot; unsigned seen; int trk; };
+  auto row_facts = [&](const float* amax) {
+    RowFacts f{0, 0xffffffffu, 0};
+    if (amax) {
+      const long mr0 = (long)m0 + wave * NRW + (lane < NRW ? lane : 0);
+      const long mr = mr0 < p.M ? mr0 : (long)p.M - 1;
+      f.trk = (mr0 < p.M && (!p.row_mask || p.row_mask[mr] != 0)) ? 1 : 0;
+      f.slot = p.row_slot ? p.row_slot[mr] : 0;
+      f.seen = *reinterpret_cast<const unsigned*>(amax + f.slot);      // (plain, cacheable: a slot only grows, a stale value is a valid lower bound)
+    }
+    return f;
+  };
+  // the row pass shared by the two residual epilogues: rows [wave NRW, + NRW) of the tile, RT at a time, from the slab:
+  //   v = slab * cs + bias + res -> dst rows (+ tracking); LN: LayerNorm_256(v) * sc -> fp16 planes into the operand image X
+  auto row_pass = [&](const rg_f32x4 cs4, const rg_f32x4 b4, const rg_f32x4 (&rpre)[NRW], const RowFacts facts, float* dstp,
+                      const long ldd, float* amax, const bool ln, const rg_f32x4 gg, const rg_f32x4 bb, const float sc) {
+    auto rows = [&](auto ps_tag) {
+      constexpr int ps = decltype(ps_tag)::value;
+      rg_f32x4 v[RT];
+      bool ok[RT];
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        const int trow = wave * NRW + ps * RT + j;
+        const long mrow = (long)m0 + trow;
+        ok[j] = mrow < p.M;
+        v[j] = *reinterpret_cast<const rg_f32x4*>(slab + rb_slab(trow, 4 * lane)) * cs4 + b4;
+        v[j] += rpre[ps * RT + j];
+        if (ok[j]) *reinterpret_cast<rg_f32x4*>(dstp + mrow * ldd + lane4) = v[j];
+      }
+      if (amax) {
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+          unsigned u = 0u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) u = max(u, __float_as_uint(v[j][e]) & 0x7fffffffu);
+          const int trk = __builtin_amdgcn_readlane(facts.trk, ps * RT + j);
+          const unsigned seen = (unsigned)__builtin_amdgcn_readlane((int)facts.seen, ps * RT + j);
+          if (trk && __builtin_amdgcn_ballot_w64(u > seen) != 0) {      // wave-uniform: nothing to do once the slot holds a larger value
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o));
+            if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(amax + __builtin_amdgcn_readlane(facts.slot, ps * RT + j)), u);
+          }
+        }
+      }
+      if (ln) {
+        float sum[RT], sq[RT];
+#pragma unroll
+        for (int j = 0; j < RT; ++j) sum[j] = wave_sum((v[j][0] + v[j][1]) + (v[j][2] + v[j][3]));
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+          const rg_f32x4 d = v[j] - sum[j] * (1.f / 256.f);
+          sq[j] = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+        }
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+          const int trow = wave * NRW + ps * RT + j;
+          const float mean = sum[j] * (1.f / 256.f);
+          const float rstd = 1.0f / sqrtf(sq[j] * (1.f / 256.f) + p.ln_eps);
+          const rg_f32x4 y = (v[j] - mean) * rstd * gg + bb;
+          const Split2 s0 = split2h_pair(y[0] * sc, y[1] * sc);
+          const Split2 s1 = split2h_pair(y[2] * sc, y[3] * sc);
+          // columns 4 lane .. + 3 = k-step lane >> 3, 16-byte slot (lane & 7) >> 1 (swizzled), its half lane & 1
+          unsigned char* d = rg_lds + (lane >> 3) * STAGE + trow * 64 + (((((lane & 7) >> 1) ^ rg_key(trow))) << 4) + (lane & 1) * 8;
+          *reinterpret_cast<rg_u32x2*>(d) = rg_u32x2{s0.h, s1.h};
+          *reinterpret_cast<rg_u32x2*>(d + A_PLANE) = rg_u32x2{s0.l, s1.l};
+        }
+      }
+    };
+    rows(std::integral_constant<int, 0>{});
+    rows(std::integral_constant<int, 1>{});
+  };
+  // the rows' residual values, requested BEFORE the accumulators go through the slab (rowgemm_wd_kernel): a uniform row base
+  // plus an unsigned lane offset -- the scalar-base form of the load, no 64-bit address register pair per row
+  auto prefetch_rows = [&](const float* res, const long ldr, rg_f32x4 (&rpre)[NRW]) {
+#pragma unroll
+    for (int j = 0; j < NRW; ++j) {
+      const long mr0 = (long)m0 + wave * NRW + j;
+      const long mr = mr0 < p.M ? mr0 : (long)p.M - 1;
+      rpre[j] = *reinterpret_cast<const rg_f32x4*>(res + mr * ldr + lane4);
+    }
+  };
+  auto acc_to_slab = [&](const rg_f32x4 (&acc)[RT][2]) {
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) slab[rb_slab(mt * 16 + kq * 4 + e, wave * 32 + nt * 16 + r16)] = acc[mt][nt][e];
+  };
+
+  // ---- phase A's epilogue: h += ... ; x = LayerNorm3(h) -> X ----
+  {
+    asm volatile("" ::"v"(warm), "v"(warm1));                  // (the kernel-start warm-up loads are long done)
+    warm = warm_lines(p.W2f, p.w2f_plane, 4096, 0);            // 256 x 1024 halves = 512 KB per plane
+    rg_f32x4 rpre[NRW];
+    const RowFacts facts = row_facts(p.amax_h);
+    prefetch_rows(p.h, p.ldh, rpre);
+    rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.cso + 4 * lane);
+    cs4 = cs4 * (1.0f / p.a_scale_o);
+    rg_f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bo) b4 = *reinterpret_cast<const rg_f32x4*>(p.bo + 4 * lane);
+    const rg_f32x4 gg = *reinterpret_cast<const rg_f32x4*>(p.ln3_g + 4 * lane);
+    const rg_f32x4 bb = *reinterpret_cast<const rg_f32x4*>(p.ln3_b + 4 * lane);
+    rg_lds_barrier();      // every wave is done reading the ring: the slab goes over it
+    acc_to_slab(acc1);
+    rg_lds_barrier();
+    row_pass(cs4, b4, rpre, facts, p.h, p.ldh, p.amax_h, true, gg, bb, p.a_scale1);
+    rg_lds_barrier();      // X is complete, the slab has been read: the upper half is free for H
+  }
+
+  // ================================ phase B: the feed-forward pair (rowffn_kernel's loop) ================================
+  // one 32-deep step: block 0, reload, counted wait (W alone), the NEXT step's A fragments requested into the other register
+  // set, block 1, reload.  `have`: this step's fragments were requested by the previous step; st_next = null where the next
+  // step's operand does not exist yet.  `waited`: the wait was done ahead of an epilogue's memory operations.
+  bool waited = true;
+  auto step = [&](auto par_tag, rg_f32x4 (&acc)[RT][2], const unsigned char* st, const unsigned char* st_next, const bool have) {
+    constexpr int par = decltype(par_tag)::value;
+    if (!have) read_a(par_tag, st);
+    __builtin_amdgcn_sched_barrier(0);
+    auto block = [&](auto nttag) {
+      mfma_block(par_tag, nttag, acc, std::integral_constant<int, 0>{});
+      if constexpr (RT > 1) mfma_block(par_tag, nttag, acc, std::integral_constant<int, 1>{});
+      if constexpr (RT > 2) mfma_block(par_tag, nttag, acc, std::integral_constant<int, 2>{});
+      if constexpr (RT > 3) mfma_block(par_tag, nttag, acc, std::integral_constant<int, 3>{});
+      if constexpr (RT > 4) mfma_block(par_tag, nttag, acc, std::integral_constant<int, 4>{});
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(par_tag, nttag);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    block(std::integral_constant<int, 0>{});
+    if (!waited) rg_wait_vmcnt<NWL>();
+    waited = false;
+    landed_w(bq[par][1][0], bq[par][1][1], bq[par ^ 1][0][0], bq[par ^ 1][0][1]);
+    if (st_next) read_a(std::integral_constant<int, par ^ 1>{}, st_next);
+    __builtin_amdgcn_sched_barrier(0);
+    block(std::integral_constant<int, 1>{});
+    advance_w();
+  };
+
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc2[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
+  const float inv1 = 1.0f / p.a_scale1;
+#pragma unroll 1
+  for (int c = 0; c < NCH; ++c) {
+    // ---- the hidden chunk ----
+    const int hc0 = c * 256 + wave * 32 + r16;
+    float csl[2], bl[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      csl[nt] = p.cs1[hc0 + 16 * nt] * inv1;
+      bl[nt] = p.b1 ? p.b1[hc0 + 16 * nt] : 0.f;
+    }
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ks += 2) {
+      step(std::integral_constant<int, 0>{}, acc1, rg_lds + ks * STAGE, rg_lds + (ks + 1) * STAGE, ks > 0 || c > 0);
+      step(std::integral_constant<int, 1>{}, acc1, rg_lds + (ks + 1) * STAGE, ks + 2 < KS ? rg_lds + (ks + 2) * STAGE : nullptr, true);
+    }
+    // ---- GELU -> planes, into stage `wave` of H (rowffn_kernel) ----
+    if (c > 0) rg_lds_barrier();      // every wave is done reading the previous chunk's H
+    {
+      unsigned char* const hs = hreg + wave * STAGE;
+      const int key = (kq & 1) << 1;
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int slot = (2 * nt + (r16 >> 3)) ^ key;
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const jv_pk2 gg2 = gelu_erf2(jv_pk2{acc1[mt][nt][e], acc1[mt][nt][e + 1]} * csl[nt] + bl[nt]) * p.h_scale;
+            const Split2 sp = split2h_pair(gg2[0], gg2[1]);
+            const int row = mt * 16 + kq * 4 + e;
+            unsigned char* d = hs + row * 64 + (slot << 4) + (r16 & 7) * 2;
+            *reinterpret_cast<unsigned short*>(d) = (unsigned short)(sp.h & 0xffffu);
+            *reinterpret_cast<unsigned short*>(d + 64) = (unsigned short)(sp.h >> 16);
+            *reinterpret_cast<unsigned short*>(d + A_PLANE) = (unsigned short)(sp.l & 0xffffu);
+            *reinterpret_cast<unsigned short*>(d + A_PLANE + 64) = (unsigned short)(sp.l >> 16);
+          }
+        }
+    }
+    rg_lds_barrier();      // H complete
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ks += 2) {
+      step(std::integral_constant<int, 0>{}, acc2, hreg + ks * STAGE, hreg + (ks + 1) * STAGE, ks > 0);
+      step(std::integral_constant<int, 1>{}, acc2, hreg + (ks + 1) * STAGE,
+           ks + 2 < KS ? hreg + (ks + 2) * STAGE : (c + 1 < NCH ? rg_lds : nullptr), true);
+    }
+  }
+  rg_wait_vmcnt<2>();      // what the next step's middle needs (if there is one), ahead of the epilogue's own memory operations
+
+  // ---- phase B's epilogue: out = h + ... (+ tracking); QKV: x' = LayerNorm1_next(out) -> X ----
+  {
+    asm volatile("" ::"v"(warm));
+    if constexpr (QKV) {
+      warm = warm_lines(p.Wqf, p.wqf_plane, 6144, 0);      // 1536 x 256 halves = 768 KB per plane
+    }
+    rg_f32x4 rpre[NRW];
+    const RowFacts facts = row_facts(p.amax_out);
+    prefetch_rows(p.h, p.ldh, rpre);
+    rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.cs2 + 4 * lane);
+    cs4 = cs4 * (1.0f / p.h_scale);
+    rg_f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.b2) b4 = *reinterpret_cast<const rg_f32x4*>(p.b2 + 4 * lane);
+    rg_f32x4 gg = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (QKV) {
+      gg = *reinterpret_cast<const rg_f32x4*>(p.ln1_g + 4 * lane);
+      bb = *reinterpret_cast<const rg_f32x4*>(p.ln1_b + 4 * lane);
+    }
+    rg_lds_barrier();      // every wave is done with X and H
+    acc_to_slab(acc2);
+    rg_lds_barrier();
+    row_pass(cs4, b4, rpre, facts, p.out, p.ldo, p.amax_out, QKV, gg, bb, QKV ? p.a_scale_q : 1.f);
+    if constexpr (QKV) rg_lds_barrier();      // X is complete, the slab has been read: the patches go over it
+  }
+
+  // ================================ phase C: q | k | v of the next block (rowgemm_wa_kernel's loop) ================================
+  if constexpr (QKV) {
+    waited = true;
+    float* const ws = slab + wave * (16 * 36);
+    const int prow = lane >> 3, pc4 = (lane & 7) * 4;
+    read_a(std::integral_constant<int, 0>{}, rg_lds);
+#pragma unroll 1
+    for (int c = 0; c < NCQ; ++c) {
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int ks = 0; ks < KS; ks += 2) {
+        step(std::integral_constant<int, 0>{}, acc1, nullptr, rg_lds + (ks + 1) * STAGE, true);
+        // (the last step of a chunk requests stage 0 again: the next chunk's first step)
+        step(std::integral_constant<int, 1>{}, acc1, nullptr, ks + 2 < KS ? rg_lds + (ks + 2) * STAGE : (c + 1 < NCQ ? rg_lds : nullptr), true);
+      }
+      if (c + 1 < NCQ) {
+        rg_wait_vmcnt<2>();
+        waited = true;
+      }
+      // the chunk's epilogue, per wave, through its private 16 x 36-float patch (rowgemm_wa_kernel): q -> fp32 rows, k / v -> planes
+      const int nw = c * 256 + wave * 32 + pc4;
+      rg_f32x4 cw = *reinterpret_cast<const rg_f32x4*>(p.csq + nw);
+      cw = cw * (1.0f / p.a_scale_q);
+      const float sc = c < 4 ? p.k_scale : p.v_scale;
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ws[(kq * 4 + e) * 36 + nt * 16 + r16] = acc1[mt][nt][e];
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int trow = mt * 16 + ps * 8 + prow;
+          const long mrow = (long)m0 + trow;
+          rg_f32x4 v = *reinterpret_cast<const rg_f32x4*>(ws + (ps * 8 + prow) * 36 + pc4) * cw;
+          if (mrow >= p.M) continue;
+          if (c < 2) {
+            *reinterpret_cast<rg_f32x4*>(p.q + mrow * p.ldq + nw) = v;
+          } else {
+            const Split2 s0 = split2h_pair(v[0] * sc, v[1] * sc);
+            const Split2 s1 = split2h_pair(v[2] * sc, v[3] * sc);
+            unsigned short* o2 = p.kv2 + mrow * p.ldkv + (nw - 512);
+            *reinterpret_cast<rg_u32x2*>(o2) = rg_u32x2{s0.h, s1.h};
+            *reinterpret_cast<rg_u32x2*>(o2 + p.kv2_plane) = rg_u32x2{s0.l, s1.l};
+          }
+        }
+      }
+    }
+  }
+  // the wrapped-around W loads of the last two steps: bq stays reserved until they have landed (rowgemm_wd_kernel)
+  rg_wait_vmcnt<0>();
+  landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
+  landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
+  asm volatile("" ::"v"(warm));
+}
+
+}  // namespace jv

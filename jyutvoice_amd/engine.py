@@ -50,6 +50,10 @@ class Engine:
         check(self.lib.jv_reserve(self._h, int(max_batch), int(max_frames), int(max_tokens)))
         self.max_batch, self.max_frames, self.max_tokens = max_batch, max_frames, max_tokens
 
+    def broken(self) -> bool:
+        """True once a failed jv_reserve could not restore the previous workspace: the context refuses every call"""
+        return not getattr(self, "_h", None) or self.lib.jv_usable(self._h) == 0
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.jv_destroy(self._h)

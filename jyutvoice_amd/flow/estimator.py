@@ -12,11 +12,22 @@ context back with `release_estimator()`; the result is read from `x`.  The refer
 
 leaves the reference's own Euler/CFG solver (solve_euler, :215-265) running unmodified on the HIP estimator.  No ONNX
 export is needed (or offered): the weights go in through load_state_dict, there is no engine file to build.
+
+Contract of the seam, stated because raw addresses carry none of it:
+  * fp32 only: the six inputs and the output are read and written as contiguous float32 (the reference's TRT profile,
+    scripts/export_onnx.py:343-346, and its `x.contiguous().data_ptr()` calls); a half-precision caller must cast first.
+  * stream order: the reference fills x / mask / mu / t on the caller's current stream and then launches on the pool's own
+    non-blocking stream with nothing ordering the two (a latent race of the reference's seam).  Here `acquire_estimator()`
+    records an event on the caller's current stream and makes the pool stream wait for it, so the estimator never reads
+    an input its producer has not finished; the reference's own `current_stream().synchronize()` orders the way back.
+  * one library context has one workspace: however many pool entries exist, calls are serialised -- `acquire_estimator()`
+    takes a lock that `release_estimator()` returns after the reference has synchronised the stream.
 """
 from __future__ import annotations
 
 import ctypes as C
 import queue
+import threading
 from typing import Dict, Tuple
 
 import torch
@@ -74,19 +85,34 @@ class HipEstimatorContext:
 
 
 class HipEstimator:
-    """`TrtContextWrapper`-shaped pool (utils/common.py:219-238): `concurrent` contexts, each with its own torch stream
-    context manager; calls on one library context are serialised by the pool size (default 1, the reference's default)."""
+    """`TrtContextWrapper`-shaped pool (utils/common.py:219-238): `trt_concurrent` contexts, each with its own torch stream
+    context manager.  All of them drive ONE library context (one workspace), so the pool hands out one at a time."""
 
     def __init__(self, engine, trt_concurrent: int = 1, device=None):
+        if trt_concurrent < 1:
+            raise ValueError("trt_concurrent must be >= 1")
         self.engine = engine
         self.trt_engine = HipEstimatorEngine()
-        device = engine.device if device is None else torch.device(device)
+        self.device = engine.device if device is None else torch.device(device)
         self.trt_context_pool: "queue.Queue" = queue.Queue(maxsize=trt_concurrent)
+        self._busy = threading.Lock()
         for _ in range(trt_concurrent):
-            self.trt_context_pool.put([HipEstimatorContext(engine), torch.cuda.stream(torch.cuda.Stream(device))])
+            stream = torch.cuda.Stream(self.device)
+            ctx = torch.cuda.stream(stream)
+            ctx.jv_stream = stream          # the raw stream behind the context manager, for the event wait below
+            self.trt_context_pool.put([HipEstimatorContext(engine), ctx])
 
     def acquire_estimator(self):
-        return self.trt_context_pool.get(), self.trt_engine
+        self._busy.acquire()                # released by release_estimator(), i.e. after the caller synchronised the stream
+        try:
+            entry = self.trt_context_pool.get()
+            # order the pool stream behind whatever produced the inputs on the caller's stream
+            entry[1].jv_stream.wait_event(torch.cuda.current_stream(self.device).record_event())
+        except BaseException:
+            self._busy.release()
+            raise
+        return entry, self.trt_engine
 
     def release_estimator(self, context, stream):
         self.trt_context_pool.put([context, stream])
+        self._busy.release()

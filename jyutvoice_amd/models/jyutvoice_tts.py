@@ -92,8 +92,19 @@ class JyutVoiceTTS:
         B, Tt = x.shape
         rt = get_runtime(self.device)
         eng = rt.ensure(B, 64, Tt)
+        # stage_events (a list, set by bench.py for its per-stage pass; None otherwise): events on the launch stream at the
+        # start, after encoder + duration predictor + length regulation, and after the CFM loop
+        ev = getattr(self, "stage_events", None)
+
+        def mark():
+            if ev is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(torch.cuda.current_stream(self.device))
+                ev.append(e)
+        mark()
         h, mu_x, logw, c = eng.encoder(x, x_lengths, lang, tone, word_pos, syllable_pos, spk_embed)
         w_ceil, y_lengths, attn, mu_y = eng.length_regulate(logw, x_lengths, mu_x, length_scale)
+        mark()
         encoder_outputs = mu_y
         if B != 1 and not batched:
             raise ValueError(f"synthesise() requires batch_size=1, got batch_size={B}. Please pass one sample at a time.")
@@ -116,6 +127,7 @@ class JyutVoiceTTS:
         t_span = 1 - torch.cos(torch.linspace(0, 1, n_timesteps + 1) * 0.5 * torch.pi)   # flow_matching.py:387-389
         dec = eng.cfm_solve(mu_y.contiguous(), lens if B > 1 else None, c, conds, n_timesteps, temperature, t_span=t_span)
         dec = dec[:, :, mel_len1:]
+        mark()
         torch.cuda.synchronize(self.device)      # the reference's rtf omits this and is meaningless on a GPU
         t = (dt.datetime.now() - t0).total_seconds()
         rtf = t * spec.SAMPLE_RATE / (dec.shape[-1] * spec.HOP_LENGTH * max(B, 1))

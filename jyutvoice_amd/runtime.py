@@ -43,7 +43,17 @@ class Runtime:
         if self.engine is None:
             self._rebuild(caps)
         else:
-            self.engine.reserve(*caps)      # workspace only: the weights of both models stay where they are
+            # workspace only: the weights of both models stay where they are.  jv_reserve is failure-atomic: if the larger
+            # workspace does not fit it restores the old one and the error propagates with self.caps unchanged; if even
+            # that fails the context refuses every call (JV_ERR_STATE), so it is dropped here and rebuilt on the next use.
+            try:
+                self.engine.reserve(*caps)
+            except Exception:
+                if self.engine.broken():
+                    self.engine.close()
+                    self.engine = None
+                    self.caps = (0, 0, 0)
+                raise
             self.caps = caps
         return self.engine
 

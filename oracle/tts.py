@@ -9,7 +9,11 @@ from . import flow, textenc
 
 
 def synthesise(sd, noise, x, x_lengths, lang, tone, word_pos, syllable_pos, spk_embed, prompt_feat=None,
-               prompt_h=None, n_timesteps=10, temperature=1.0, length_scale=1.0, batched=False):
+               prompt_h=None, n_timesteps=10, temperature=1.0, length_scale=1.0, batched=False, timings=None):
+    """timings (optional dict): wall-clock seconds of the two stages are added to timings["encoder_dp"] / timings["cfm"]
+    (bench.py's per-stage CPU baseline)"""
+    import time
+    t0 = time.perf_counter()
     c = F.linear(F.normalize(spk_embed, dim=1), sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"])
     h, mu_x, x_mask = textenc.text_encoder(sd, x, x_lengths, lang, tone, word_pos, syllable_pos, spk_embed)
     logw = textenc.duration_predictor(sd, h, x_mask, spk_embed)
@@ -31,7 +35,11 @@ def synthesise(sd, noise, x, x_lengths, lang, tone, word_pos, syllable_pos, spk_
         conds = torch.zeros_like(mu_y)
         lens = y_lengths
     mask = (torch.arange(mu_y.shape[2]).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(1).to(mu_y.dtype)
+    t1 = time.perf_counter()
     dec = flow.cfm_solve(sd, noise, mu_y, mask, c, conds, n_timesteps, temperature)
     dec = dec[:, :, mel_len1:]
+    if timings is not None:
+        timings["encoder_dp"] = timings.get("encoder_dp", 0.0) + (t1 - t0)
+        timings["cfm"] = timings.get("cfm", 0.0) + (time.perf_counter() - t1)
     return {"encoder_outputs": encoder_outputs, "decoder_outputs": dec, "attn": attn.unsqueeze(1),
             "mel": dec, "mel_lengths": y_lengths, "logw": logw, "w_ceil": w_ceil, "mu_x": mu_x, "x": h}

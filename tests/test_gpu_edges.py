@@ -127,3 +127,25 @@ def test_runtime_grows_without_reloading(tts_sd, hift_sd):
     caps = rt.caps
     e1 = rt.ensure(caps[0] + 1, caps[1] + 64, caps[2] + 32)
     assert e1 is e0 and rt.caps[0] == caps[0] + 1
+
+
+def test_reserve_is_failure_atomic(eng):
+    """a jv_reserve whose workspace cannot be allocated (here: capacities worth terabytes) must leave the context
+    at its previous capacities with a complete workspace -- not half-created buffers behind enlarged caps -- so the next call
+    at an old shape computes the same bits, and a shape beyond the old capacity is still refused with JV_ERR_SHAPE"""
+    from jyutvoice_amd._lib import JvError
+    g = torch.Generator().manual_seed(11)
+    mu = torch.randn(2, 80, 100, generator=g).cuda()
+    spks = torch.randn(2, 80, generator=g).cuda()
+    cond = torch.zeros(2, 80, 100).cuda()
+    lens = torch.tensor([100, 61], dtype=torch.int32).cuda()
+    caps = (eng.max_batch, eng.max_frames, eng.max_tokens)
+    want = eng.cfm_solve(mu, lens, spks, cond, 3, 1.0).cpu()
+    with pytest.raises(JvError, match="capacities unchanged"):
+        eng.reserve(3000, 150000, 64)
+    assert not eng.broken()
+    assert (eng.max_batch, eng.max_frames, eng.max_tokens) == caps       # the Python mirror did not move either
+    assert torch.equal(eng.cfm_solve(mu, lens, spks, cond, 3, 1.0).cpu(), want)
+    with pytest.raises(JvError, match="capacity"):
+        eng.cfm_solve(torch.randn(caps[0] + 1, 80, 64).cuda(), None, torch.randn(caps[0] + 1, 80).cuda(),
+                      torch.zeros(caps[0] + 1, 80, 64).cuda(), 2, 1.0)

@@ -315,3 +315,29 @@ def test_fused_feed_forward_equals_two_launches(monkeypatch):
     for f, s in zip(fused, split):
         assert torch.isfinite(f).all()
         assert torch.equal(f, s), float((f - s).abs().max())
+
+
+def test_fused_block_equals_separate_launches(monkeypatch):
+    """rowblock_kernel (to_out + residual + LayerNorm3 -> feed-forward pair + residual -> the next block's LayerNorm1 ->
+    q | k | v in one launch, the LayerNorm planes kept in LDS) against the three row-owning launches it replaces
+    (JV_NO_BLOCK_FUSE=1: rowgemm_wd<res,ln>, rowffn, rowgemm_wa<qkv>): the same K order in every sum and the same epilogue
+    expressions -- the mels must be equal bit for bit, at a tile height of 5 (32 utterances), 2 (ragged 8) and 4 (ragged 20,
+    with a last workgroup that is partly past the end)"""
+    import jyutvoice_amd
+    from jyutvoice_amd import synth
+    sd = synth.tts_state_dict(fixed_duration=1.5)
+    keys = ("x", "x_lengths", "lang", "tone", "word_pos", "syllable_pos", "spk_embed")
+    cases = [synth.batch(32, 150), synth.batch(8, 150, first_index=40, lengths=[150 - 11 * i for i in range(8)]),
+             synth.batch(20, 131, first_index=7, lengths=[131 - 3 * i for i in range(20)])]
+
+    def run():
+        tts, _ = jyutvoice_amd.build_default("cuda:0")
+        tts.load_state_dict(sd)
+        return [tts.synthesise(*[b[k] for k in keys], None, n_timesteps=2, batched=True)["mel"].cpu() for b in cases]
+
+    fused = run()
+    monkeypatch.setenv("JV_NO_BLOCK_FUSE", "1")
+    split = run()
+    for f, s in zip(fused, split):
+        assert torch.isfinite(f).all()
+        assert torch.equal(f, s), float((f - s).abs().max())

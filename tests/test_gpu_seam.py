@@ -79,6 +79,51 @@ def test_trt_seam_protocol(eng, tts_sd):
     est.release_estimator(*ctx2)
 
 
+def test_trt_seam_orders_pool_stream_after_producer(eng, tts_sd):
+    """solve_euler fills x / mu / t on the caller's current stream and forward_estimator then launches on the
+    pool's own non-blocking stream.  acquire_estimator() must order that stream behind the producer: here the inputs are
+    produced on the current stream BEHIND a long-running kernel (so they are certainly not ready when the host reaches
+    execute_async_v3), and the result must still be the estimator of the finished inputs.  The pool also serialises: a
+    second acquire blocks until release."""
+    import threading
+
+    from jyutvoice_amd.flow.estimator import HipEstimator
+    from oracle import flow as oflow
+    est = HipEstimator(eng, trt_concurrent=2)
+    T = 48
+    host = cfg_inputs(T, 900)
+    want = oflow.estimator(tts_sd, *host)
+    x, mask, mu, t, spks, cond = (torch.empty_like(v, device="cuda") for v in host)
+    pinned = [v.pin_memory() for v in host]
+    big = torch.randn(4096, 4096, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(6):
+        big = big @ big * 1e-3                      # ~ms of queued work ahead of the producers
+    for dst, src in zip((x, mask, mu, t, spks, cond), pinned):
+        dst.copy_(src, non_blocking=True)           # the producers: queued on the current stream, not finished
+    [context, stream], engine = est.acquire_estimator()
+    got_second = []
+    th = threading.Thread(target=lambda: got_second.append(est.acquire_estimator()))
+    th.start()
+    with stream:
+        for name, v in zip(("x", "mask", "mu", "t", "spks", "cond"), (x, mask, mu, t, spks, cond)):
+            assert context.set_input_shape(name, tuple(v.shape))
+        ptrs = [v.data_ptr() for v in (x, mask, mu, t, spks, cond)] + [x.data_ptr()]
+        for i, ptr in enumerate(ptrs):
+            assert context.set_tensor_address(engine.get_tensor_name(i), ptr)
+        assert context.execute_async_v3(torch.cuda.current_stream().cuda_stream) is True
+        torch.cuda.current_stream().synchronize()
+    th.join(timeout=0.2)
+    assert th.is_alive() and not got_second         # the second taker waits for the release
+    est.release_estimator(context, stream)
+    th.join(timeout=10)
+    assert not th.is_alive() and len(got_second) == 1
+    est.release_estimator(*got_second[0][0])
+    assert md(x, want) <= 1e-4
+    with pytest.raises(ValueError):
+        HipEstimator(eng, trt_concurrent=0)
+
+
 def test_integration_md_stub_runs_verbatim(eng, tts_sd, monkeypatch):
     """the reference-side binding, executed exactly as printed"""
     from jyutvoice_amd import _lib

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Build-time check of the hand-managed register double buffer of the W-direct kernels: rowgemm_wd_kernel, rowgemm_wa_kernel,
-rowffn_kernel (rowgemm_kernel.h) and rowconv_wd_kernel (rowconv_kernel.h).
+rowffn_kernel (rowgemm_kernel.h), rowconv_wd_kernel (rowconv_kernel.h) and rowblock_kernel (rowblock_kernel.h).
 
 The weight fragments are loaded by inline asm (global_load_dwordx4) and waited for by a counted s_waitcnt the compiler does
 not know about.  That is only sound if, in the generated code, the destination registers of those loads are touched by
 nothing except (a) the asm loads, (b) v_mfma instructions reading them as an operand, (c) code ahead of the register's
 first load (the straight-line prologue, where nothing is in flight in it yet).  A register-allocator copy or spill of one of them while a load is in flight would read stale data without
-any tool noticing.  This script compiles rowgemm.hip to assembly and asserts exactly that for every instantiation.
+any tool noticing.  This script compiles rowgemm.hip and rowblock.hip to assembly and asserts exactly that for every instantiation.
 
 usage: python tools/check_rowgemm_isa.py   (exit code 0 = clean)"""
 import os
@@ -16,7 +16,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "jyutvoice_amd", "csrc", "rowgemm.hip")
+SRCS = [os.path.join(ROOT, "jyutvoice_amd", "csrc", f) for f in ("rowgemm.hip", "rowblock.hip")]
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-fno-slp-vectorize", "-x", "hip", "--cuda-device-only", "-S"]
 
@@ -89,21 +89,23 @@ def check_kernel(name, body):
 
 
 def main():
+    s = ""
     with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "rowgemm.s")
-        r = subprocess.run([CLANG] + FLAGS + ["-o", out, SRC], capture_output=True, text=True)
-        if r.returncode != 0:
-            print(r.stderr[-3000:])
-            return 2
-        s = open(out).read()
-        # -S does not run the assembler over the inline asm: an operand the assembler rejects only shows with -c
-        r = subprocess.run([CLANG] + [f for f in FLAGS if f != "-S"] + ["-c", "-o", os.path.join(d, "rowgemm.o"), SRC],
-                           capture_output=True, text=True)
-        if r.returncode != 0:
-            print(r.stderr[-3000:])
-            return 2
+        for src in SRCS:
+            out = os.path.join(d, os.path.basename(src) + ".s")
+            r = subprocess.run([CLANG] + FLAGS + ["-o", out, src], capture_output=True, text=True)
+            if r.returncode != 0:
+                print(r.stderr[-3000:])
+                return 2
+            s += open(out).read()
+            # -S does not run the assembler over the inline asm: an operand the assembler rejects only shows with -c
+            r = subprocess.run([CLANG] + [f for f in FLAGS if f != "-S"] + ["-c", "-o", os.path.join(d, os.path.basename(src) + ".o"), src],
+                               capture_output=True, text=True)
+            if r.returncode != 0:
+                print(r.stderr[-3000:])
+                return 2
     n_k = n_bad = 0
-    for m in re.finditer(r"^(_ZN2jv\d+(rowgemm_wd_kernel|rowgemm_wa_kernel|rowffn_kernel|rowconv_wd_kernel)\w+):\s*;.*?\n(.*?)\.end_amdhsa_kernel", s, re.S | re.M):
+    for m in re.finditer(r"^(_ZN2jv\d+(rowgemm_wd_kernel|rowgemm_wa_kernel|rowffn_kernel|rowconv_wd_kernel|rowblock_kernel)\w+):\s*;.*?\n(.*?)\.end_amdhsa_kernel", s, re.S | re.M):
         name, body = m.group(1), m.group(3)
         body = body.split("s_endpgm")[0]
         n_loads, bad = check_kernel(name, body)

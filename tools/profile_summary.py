@@ -17,6 +17,9 @@ def short(name):
     if m:
         epi = {"0": "", "1": ",gelu", "2": ",res", "3": ",res,ln", "4": ",qkv"}.get(m.group(2), "")
         return f"rowgemm_h3<{16 * int(m.group(1))}x256{epi}>"
+    m = re.search(r"rowblock_kernel<(\d+), (true|false|0|1)>", name)
+    if m:
+        return f"rowblock_h3<{16 * int(m.group(1))}x256{',qkv' if m.group(2) in ('true', '1') else ''}>"
     m = re.search(r"rowffn_kernel<(\d+)>", name)
     if m:
         return f"rowffn_h3<{16 * int(m.group(1))}x256>"
@@ -93,7 +96,10 @@ for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
 
 if traffic:   # per-launch HBM bytes by kernel, read back by bench.py for roofline.traffic
     import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from jyutvoice_amd.build import source_hash
     with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
-        json.dump({"source": f"tools/profile.sh {os.path.basename(out)}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE, "
+        json.dump({"csrc_sha16": source_hash(),      # bench.py quotes these figures only for the build they were measured on
+                   "source": f"tools/profile.sh {os.path.basename(out)}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE, "
                              "separate passes over bench.py --steps 1, bytes per launch",
                    "kernels": traffic}, fh, indent=1, sort_keys=True)
