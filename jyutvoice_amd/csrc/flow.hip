@@ -7,6 +7,7 @@
 // 14 x (3 conv GEMMs) + 56 x (2 LayerNorm + 4 GEMM + 1 attention) + 4 tail launches, all enqueued on the
 // caller's stream with no host synchronisation (graph-capturable).
 #include <math.h>
+#include <stdio.h>
 
 #include <algorithm>
 #include <vector>
@@ -43,6 +44,7 @@ struct FlowWs {
   float* amax = nullptr;
   int amax_stride = 0;      // floats per buffer = 2 * max_batch
   float* partial = nullptr;      // [8][PARTIAL_ROWS][256] split-K partial sums (short M only)
+  unsigned long long* rb_stamps = nullptr;      // tuning builds, JV_RB_STAMPS: rowblock_kernel's phase stamps of the last launch
   float *d = nullptr;                                                 // [rows,80]
   float *tsin = nullptr, *t1 = nullptr, *tmish = nullptr, *temb = nullptr;
   float *t_dev = nullptr, *t_table = nullptr, *dt_table = nullptr;
@@ -397,7 +399,8 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
         JV_TRY(rowgemm(a, RG_QKV, st));
       }
       at.ld = 512; at.kv2 = kv2; at.kv2_plane = R * 1024; at.kv_ld = 1024;
-      JV_TRY(attention64_planes(at, st));
+      if (at.chunk == 0 && c.attn_rows) JV_TRY(attention64_rows(at, st));      // one workgroup per head, 80 queries per wave (opt-in)
+      else JV_TRY(attention64_planes(at, st));
     } else {
       a.out = w.qkv; a.ldo = 1536;
       JV_TRY(rowgemm(a, RG_PLAIN, st));
@@ -425,6 +428,10 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
         f.q = w.qkv; f.ldq = 512; f.kv2 = kv2; f.kv2_plane = R * 1024; f.ldkv = 1024; f.k_scale = next->k_scale; f.v_scale = next->v_scale;
       }
       *qkv_next = qkv;
+      if (tuning_env("JV_RB_STAMPS")) {
+        if (!w.rb_stamps) JV_TRY(ws_alloc(c, 2 * 1024 * 48 * sizeof(unsigned long long), reinterpret_cast<void**>(&w.rb_stamps)));
+        f.stamps = w.rb_stamps + (qkv ? 0 : 1024 * 48);
+      }
       return rowblock(f, qkv, st);
     }
     a = rg_args(w.att, 512, b.out);      // h += to_out(att); ln = LayerNorm3(h)
@@ -676,6 +683,24 @@ int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spk
     for (int s = first; s < n_timesteps; ++s) JV_HIP(hipGraphLaunch(sg->exec, w.gstream));
     JV_HIP(hipEventRecord(w.ev_out, w.gstream));
     JV_HIP(hipStreamWaitEvent(st, w.ev_out, 0));
+  }
+  if (w.rb_stamps && tuning_env("JV_RB_STAMPS")) {      // tuning aid: phase breakdown of the LAST rowblock launch (a block without q|k|v)
+    JV_HIP(hipStreamSynchronize(st));
+    const int nwg = (int)std::min<long>(1024, cdivl(g.M, 16 * std::max(1, rowgemm_tile((int)g.M))));
+    std::vector<unsigned long long> hs((size_t)nwg * 48);
+    for (int v = 0; v < 2; ++v) {
+      JV_HIP(hipMemcpy(hs.data(), w.rb_stamps + v * 1024 * 48, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[rowblock stamps%s] %d workgroups; median s_memtime ticks (100 MHz) since start:", v ? "" : ",qkv", nwg);
+      for (int i = 1; i < 48; ++i) {
+        std::vector<long> d;
+        for (int b = 0; b < nwg; ++b)
+          if (hs[(size_t)b * 48 + i] > hs[(size_t)b * 48]) d.push_back((long)(hs[(size_t)b * 48 + i] - hs[(size_t)b * 48]));
+        if (d.empty()) continue;
+        std::sort(d.begin(), d.end());
+        fprintf(stderr, " %d:%ld", i, d[d.size() / 2]);
+      }
+      fprintf(stderr, "\n");
+    }
   }
   return rows_to_cf(w.x, 80, 0, FLOW_G, g.S, mel, 80L * T, B, 80, T, lens_dev ? w.lens2 : nullptr, st);
 }

@@ -199,6 +199,7 @@ struct AttnArgs {
 };
 int attention64(const AttnArgs& a, hipStream_t st);
 int attention64_planes(const AttnArgs& a, hipStream_t st);
+int attention64_rows(const AttnArgs& a, hipStream_t st);      // attention_r.hip: attention64_planes' contract, chunk == 0 only
 
 // ---- row-wise / elementwise kernels (rowops.hip) -------------------------------------------------
 // out = LayerNorm_C(x (+ add)) * g + b, optional ReLU, rows with rowmask_out == 0 written as zero

@@ -8,66 +8,39 @@
 
 namespace jv {
 
-// erf(a) in fp32 without branches: two minimax fits (|a| <= 0.927734375: odd polynomial; beyond: 1 - exp(-poly(|a|))) whose
-// coefficients are N. Juffa's published single-precision erff (< 1 ulp); here both are evaluated and selected, and the
-// exponential is the raw v_exp_f32.  Measured against fp64 over [-6, 6]: 5.8e-8 absolute, 8.8e-8 relative -- the accuracy of
-// libm's erff, at ~20 VALU instructions instead of the device library's branchy ~60 (the GELU epilogue of ff.net.0 was 30 %
-// of that GEMM's time).
-__device__ __forceinline__ float erf_fast(const float a) {
-  const float t = fabsf(a), s = a * a;
-  float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
-  const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
-  r = fmaf(r, s, u);
-  r = fmaf(r, t, -1.06777877e-1f);
-  r = fmaf(r, t, -6.34846687e-1f);
-  r = fmaf(r, t, -1.28717512e-1f);
-  r = fmaf(r, t, -t);
-  r = 1.0f - __builtin_amdgcn_exp2f(r * 1.44269504088896340736f);
-  const float big = copysignf(r, a);
-  float q = -5.96761703e-4f;
-  q = fmaf(q, s, 4.99119423e-3f);
-  q = fmaf(q, s, -2.67681349e-2f);
-  q = fmaf(q, s, 1.12819925e-1f);
-  q = fmaf(q, s, -3.76125336e-1f);
-  q = fmaf(q, s, 1.28379166e-1f);
-  const float small = fmaf(q, a, a);
-  return t > 0.927734375f ? big : small;      // NaN: the comparison is false, `small` propagates it
+// Exact (erf) GELU, 0.5 v (1 + erf(v / sqrt 2)), in ONE branch-free chain of 14 operations:
+//     gelu(v) = relu(v) - u E(u),   u = |v|,   E(u) = erfc(u / sqrt 2) / 2 = 2^Q(u)
+// with Q a degree-9 polynomial (weighted minimax fit of log2 E on [0, 6.5], weight u E ln 2 = the sensitivity of the result;
+// tools/fit_gelu.py holds the fit and the error measurement) and the raw v_exp_f32.  Beyond u = 6.5 the correction term is
+// frozen at 6.5 E(6.5) = 1e-9 (the true one is smaller still); relu is written (v + |v|) / 2 so that a NaN propagates (v_max
+// would return the other operand).  Measured against fp64 over [-12, 12] and at +-30, 100, 1e4: absolute error <= 4.4e-8
+// for v < 0, relative error <= 1.9e-7 for v > 0.05 -- the accuracy of the two-branch form it replaces (rounds 1-2: N. Juffa's
+// erff pair evaluated both ways and selected, 27 operations: 8.3e-8 / 1.8e-7) and tighter than torch's own fp32 gelu
+// (1.1e-6 / 3.8e-7), at half the operations: the GELU pass between
+// the two feed-forward GEMMs is pure VALU work with the matrix pipe idle (20 % of the fused block launch in the phase stamps).
+__device__ __forceinline__ float gelu_erf(const float v) {
+  const float u = fminf(fabsf(v), 6.5f);
+  float q = 3.9286530295612465e-07f;
+  q = fmaf(q, u, -7.801393621775787e-06f);
+  q = fmaf(q, u, 6.441200821427628e-05f);
+  q = fmaf(q, u, -0.00025067193200811744f);
+  q = fmaf(q, u, -4.676209937315434e-05f);
+  q = fmaf(q, u, 0.0069969831965863705f);
+  q = fmaf(q, u, -0.0524740107357502f);
+  q = fmaf(q, u, -0.45920976996421814f);
+  q = fmaf(q, u, -1.151105523109436f);
+  q = fmaf(q, u, -1.0f);
+  const float w = u * __builtin_amdgcn_exp2f(q);
+  return fmaf(0.5f, v + fabsf(v), -w);
 }
-__device__ __forceinline__ float gelu_erf(const float v) { return 0.5f * v * (1.f + erf_fast(v * 0.70710678118654752440f)); }
 
-// Two values at once with packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32: two IEEE operations per lane and instruction):
-// the same operations in the same order as erf_fast / gelu_erf, so the same bits, in ~30 VALU instructions per pair instead
-// of ~44.  For phases in which every wave of the workgroup runs the activation and the matrix pipe is idle anyway (the GELU
-// pass between the two feed-forward GEMMs, rowblock_kernel.h); beside MFMAs the packed forms issue slower than scalar pairs.
-typedef float jv_pk2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ jv_pk2 erf_fast2(const jv_pk2 a) {
-  auto bc = [](const float x) { return jv_pk2{x, x}; };
-  auto fma2 = [](const jv_pk2 x, const jv_pk2 y, const jv_pk2 z) { return __builtin_elementwise_fma(x, y, z); };
-  const jv_pk2 t = __builtin_elementwise_abs(a), s = a * a;
-  jv_pk2 r = fma2(bc(-1.72853470e-5f), t, bc(3.83197126e-4f));
-  const jv_pk2 u = fma2(bc(-3.88396438e-3f), t, bc(2.42546219e-2f));
-  r = fma2(r, s, u);
-  r = fma2(r, t, bc(-1.06777877e-1f));
-  r = fma2(r, t, bc(-6.34846687e-1f));
-  r = fma2(r, t, bc(-1.28717512e-1f));
-  r = fma2(r, t, -t);
-  r = r * 1.44269504088896340736f;
-  jv_pk2 ex = {__builtin_amdgcn_exp2f(r[0]), __builtin_amdgcn_exp2f(r[1])};
-  ex = 1.0f - ex;
-  const jv_pk2 big = {copysignf(ex[0], a[0]), copysignf(ex[1], a[1])};
-  jv_pk2 q = bc(-5.96761703e-4f);
-  q = fma2(q, s, bc(4.99119423e-3f));
-  q = fma2(q, s, bc(-2.67681349e-2f));
-  q = fma2(q, s, bc(1.12819925e-1f));
-  q = fma2(q, s, bc(-3.76125336e-1f));
-  q = fma2(q, s, bc(1.28379166e-1f));
-  const jv_pk2 small = fma2(q, a, a);
-  return jv_pk2{t[0] > 0.927734375f ? big[0] : small[0], t[1] > 0.927734375f ? big[1] : small[1]};
-}
-__device__ __forceinline__ jv_pk2 gelu_erf2(const jv_pk2 v) { return 0.5f * v * (1.f + erf_fast2(v * 0.70710678118654752440f)); }
-
-// sum over the 64 lanes of a wave, returned in every lane: four DPP butterflies inside each row of 16 lanes (VALU only),
-// then the four row totals through v_readlane -- no LDS round trips (__shfl_xor is ds_bpermute: six dependent ones)
+// sum over the 64 lanes of a wave, returned in every lane: four DPP butterflies inside each row of 16 lanes, then the four
+// row totals R0..R3 combined as (R0 + R1) + (R2 + R3) with gfx950's row / half exchanges (v_permlane16_swap: rows 1 and 3 of
+// the first operand trade places with rows 0 and 2 of the second; v_permlane32_swap: the same for the two halves) -- all
+// VALU, no LDS round trips (__shfl_xor is ds_bpermute) and no trip through SGPRs.  (Round 2 read the row totals with four
+// v_readlane and added them as wave-uniform values: the same association, hence the same bits, but each readlane result
+// costs hazard wait states and a v_mov before a VALU add can take two of them -- measured in the row-owning kernels'
+// LayerNorm epilogues, where nothing hides latency: 20 reductions per wave.)
 __device__ __forceinline__ float wave_sum(float x) {
   auto dpp = [](float v, auto ctrl) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
@@ -76,10 +49,10 @@ __device__ __forceinline__ float wave_sum(float x) {
   x += dpp(x, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
   x += dpp(x, std::integral_constant<int, 0x141>{});     // row_half_mirror
   x += dpp(x, std::integral_constant<int, 0x140>{});     // row_mirror
-  const int b = __builtin_bit_cast(int, x);
-  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
-  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
-  return (r0 + r1) + (r2 + r3);
+  const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);      // even row + odd row, in every lane of both
+  const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);   // lower half + upper half
 }
 
 // activations as the reference's PyTorch ops compute them (exact erf GELU, ...).  Mish x tanh(softplus x) is evaluated
@@ -175,7 +148,7 @@ __device__ __forceinline__ Split2 split2h_pair(const float x0, const float x1) {
   // x * 1 - h with a 1.0 the optimiser cannot see through: the residual then is ONE v_fma_mix_f32 per element (h read as
   // fp16 in place, same exactly-rounded x - h) instead of v_cvt_f32_f16 + v_sub_f32
   float one = 1.0f;
-  asm volatile("" : "+v"(one));
+  asm("" : "+v"(one));      // (not volatile: a volatile asm per pair chains the pairs of an unrolled loop in program order)
   const float r0 = fmaf(x0, one, -(float)h[0]), r1 = fmaf(x1, one, -(float)h[1]);
   const jv_f32x2 r = {r0, r1};
   const jv_f16x2 l = __builtin_convertvector(r, jv_f16x2);

@@ -70,6 +70,7 @@ struct RowBlockArgs {
   int ldkv;
   float k_scale, v_scale;
   long alg_rows;
+  unsigned long long* stamps;      // tuning aid (JV_RB_STAMPS, tuning builds): [workgroup][48] s_memtime at the phase boundaries
 };
 
 template <int RT> constexpr int rb_lds_bytes() { return 16 * rgw_stage_bytes<RT>(); }
@@ -97,11 +98,26 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   const int r16 = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.x * R;
   const unsigned lane4 = 4u * (unsigned)lane;      // this lane's four columns in the row passes
+  int stamp_i = 0;
+  auto stamp = [&]() {      // (compiled out unless JV_TUNING)
+    if (JV_STAMP(p)) {
+      if (tid == 0 && stamp_i < 32) p.stamps[(long)blockIdx.x * 48 + stamp_i] = __builtin_amdgcn_s_memtime();
+      ++stamp_i;
+    }
+  };
+  stamp();      // 0: start
+  int xstamp_i = 32;
+  auto xstamp = [&]() {      // detail stamps inside the epilogues: slots 32..47
+    if (JV_STAMP(p)) {
+      if (tid == 0 && xstamp_i < 48) p.stamps[(long)blockIdx.x * 48 + xstamp_i] = __builtin_amdgcn_s_memtime();
+      ++xstamp_i;
+    }
+  };
   unsigned char* const hreg = rg_lds + H_OFF;
   float* const slab = reinterpret_cast<float*>(hreg);
 
   // ---- L2 warm-up of the weights (rowgemm_kernel): the workgroups that share an XCD touch every 128-byte line of a matrix
-  // once.  Wo and W1 at kernel start; W2 while phase A's epilogue runs; Wqkv while phase B's does -- a matrix touched a
+  // once.  Wo and W1 at kernel start; W2 while phase A's epilogue runs; Wqkv at the last GELU pass -- a matrix touched a
   // hundred microseconds ahead would be gone from a 4 MB L2 by the time its phase starts.
   const int wgrp = blockIdx.x >> 3, wngrp = (gridDim.x + 7) >> 3;
   auto warm_lines = [&](const unsigned short* base, long plane_halves, long lines_per_plane, int round) -> float {
@@ -117,6 +133,24 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   };
   float warm = warm_lines(p.Wof, p.wof_plane, 2048, 0);      // 256 x 512 halves = 256 KB per plane
   float warm1 = warm_lines(p.W1f, p.w1f_plane, 4096, 0);     // 1024 x 256 halves = 512 KB per plane
+
+  // Per-row facts of the tracking (mask, slot, the slots' current maxima): lane j < NRW loads those of the wave's row j and
+  // the row passes broadcast them with v_readlane.  Loaded HERE, at kernel start, where the dependent chain (row -> slot ->
+  // maximum) hides behind the prologue's own waits: in front of an epilogue it was two L2 round trips with nothing to
+  // overlap them (3 - 4.6 us per epilogue in the phase stamps).  A maximum read early is merely stale, i.e. a valid lower
+  // bound.  (Asked for row by row these are wave-uniform values: the compiler then made 2 NRW scalar-path loads of them,
+  // each behind its own branch and s_waitcnt vmcnt(0).)
+  struct RowFacts { int slot; unsigned seen; int trk; };
+  RowFacts facts_h{0, 0xffffffffu, 0}, facts_o{0, 0xffffffffu, 0};
+  if (p.amax_h || p.amax_out) {
+    const long mr0 = (long)m0 + wave * NRW + (lane < NRW ? lane : 0);
+    const long mr = mr0 < p.M ? mr0 : (long)p.M - 1;
+    const int trk = (mr0 < p.M && (!p.row_mask || p.row_mask[mr] != 0)) ? 1 : 0;
+    const int slot = p.row_slot ? p.row_slot[mr] : 0;
+    // (plain, cacheable loads: a slot only grows)
+    if (p.amax_h) facts_h = RowFacts{slot, *reinterpret_cast<const unsigned*>(p.amax_h + slot), trk};
+    if (p.amax_out) facts_o = RowFacts{slot, *reinterpret_cast<const unsigned*>(p.amax_out + slot), trk};
+  }
 
   // ---- phase A operand: the attention planes through a 3-stage ring in the upper half (rowgemm_wd_kernel) ----
   const unsigned short* cur[PPW];
@@ -240,6 +274,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
   landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
   rg_barrier();
+  stamp();      // 1: prologue done
   read_a(std::integral_constant<int, 0>{}, hreg);
 
   rg_f32x4 acc1[RT][2], acc2[RT][2];
@@ -299,26 +334,11 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
       stepA(std::integral_constant<int, 1>{});
     }
   }
+  stamp();      // 2: phase A loop done
   // what the first step of phase B waits for in its middle -- W0(17), W1(16) -- has only W1(17) behind it so far; counted
   // HERE, ahead of the epilogue's own loads and stores (vmcnt retires in order: counting behind them would wait for them)
   rg_wait_vmcnt<2>();
 
-  // Per-row facts of the tracking (mask, slot, the slot's current maximum): lane j < NRW loads those of the wave's row j --
-  // three vector loads per epilogue, the last dependent on the second -- and the row pass broadcasts them with v_readlane.
-  // (Asked for row by row they are wave-uniform values: the compiler turned them into 2 NRW scalar-path loads, each behind
-  // its own branch and s_waitcnt vmcnt(0) -- a serial chain of twenty L2 round trips per epilogue.)
-  struct RowFacts { int slot; unsigned seen; int trk; };
-  auto row_facts = [&](const float* amax) {
-    RowFacts f{0, 0xffffffffu, 0};
-    if (amax) {
-      const long mr0 = (long)m0 + wave * NRW + (lane < NRW ? lane : 0);
-      const long mr = mr0 < p.M ? mr0 : (long)p.M - 1;
-      f.trk = (mr0 < p.M && (!p.row_mask || p.row_mask[mr] != 0)) ? 1 : 0;
-      f.slot = p.row_slot ? p.row_slot[mr] : 0;
-      f.seen = *reinterpret_cast<const unsigned*>(amax + f.slot);      // (plain, cacheable: a slot only grows, a stale value is a valid lower bound)
-    }
-    return f;
-  };
   // the row pass shared by the two residual epilogues: rows [wave NRW, + NRW) of the tile, RT at a time, from the slab:
   //   v = slab * cs + bias + res -> dst rows (+ tracking); LN: LayerNorm_256(v) * sc -> fp16 planes into the operand image X
   auto row_pass = [&](const rg_f32x4 cs4, const rg_f32x4 b4, const rg_f32x4 (&rpre)[NRW], const RowFacts facts, float* dstp,
@@ -360,11 +380,17 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
           const rg_f32x4 d = v[j] - sum[j] * (1.f / 256.f);
           sq[j] = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
         }
+        // 1 / sqrt(var + eps) of the RT rows in ONE evaluation: lane j computes row j's (the correctly rounded division and
+        // square root are ~30 instructions; per row, on wave-uniform values, that was a third of this pass), then broadcast
+        float var_l = sq[0];
+#pragma unroll
+        for (int j = 1; j < RT; ++j) var_l = lane == j ? sq[j] : var_l;
+        const float rstd_l = 1.0f / sqrtf(var_l * (1.f / 256.f) + p.ln_eps);
 #pragma unroll
         for (int j = 0; j < RT; ++j) {
           const int trow = wave * NRW + ps * RT + j;
           const float mean = sum[j] * (1.f / 256.f);
-          const float rstd = 1.0f / sqrtf(sq[j] * (1.f / 256.f) + p.ln_eps);
+          const float rstd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rstd_l), j));
           const rg_f32x4 y = (v[j] - mean) * rstd * gg + bb;
           const Split2 s0 = split2h_pair(y[0] * sc, y[1] * sc);
           const Split2 s1 = split2h_pair(y[2] * sc, y[3] * sc);
@@ -401,21 +427,27 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   {
     asm volatile("" ::"v"(warm), "v"(warm1));                  // (the kernel-start warm-up loads are long done)
     warm = warm_lines(p.W2f, p.w2f_plane, 4096, 0);            // 256 x 1024 halves = 512 KB per plane
-    rg_f32x4 rpre[NRW];
-    const RowFacts facts = row_facts(p.amax_h);
-    prefetch_rows(p.h, p.ldh, rpre);
+    // (the per-column constants FIRST: vmcnt retires in order, so the first use of one of them must not have the rows'
+    // residual loads in front of it -- it then waited for all ten, ~2 us, before the slab pass had even begun)
     rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.cso + 4 * lane);
-    cs4 = cs4 * (1.0f / p.a_scale_o);
     rg_f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bo) b4 = *reinterpret_cast<const rg_f32x4*>(p.bo + 4 * lane);
     const rg_f32x4 gg = *reinterpret_cast<const rg_f32x4*>(p.ln3_g + 4 * lane);
     const rg_f32x4 bb = *reinterpret_cast<const rg_f32x4*>(p.ln3_b + 4 * lane);
+    cs4 = cs4 * (1.0f / p.a_scale_o);
+    rg_f32x4 rpre[NRW];
+    prefetch_rows(p.h, p.ldh, rpre);
+    xstamp();      // 18: loads requested
     rg_lds_barrier();      // every wave is done reading the ring: the slab goes over it
+    xstamp();      // 19
     acc_to_slab(acc1);
     rg_lds_barrier();
-    row_pass(cs4, b4, rpre, facts, p.h, p.ldh, p.amax_h, true, gg, bb, p.a_scale1);
+    xstamp();      // 20: slab written
+    row_pass(cs4, b4, rpre, facts_h, p.h, p.ldh, p.amax_h, true, gg, bb, p.a_scale1);
+    xstamp();      // 21: row pass done (this wave)
     rg_lds_barrier();      // X is complete, the slab has been read: the upper half is free for H
   }
+  stamp();      // 3: epilogue A done
 
   // ================================ phase B: the feed-forward pair (rowffn_kernel's loop) ================================
   // one 32-deep step: block 0, reload, counted wait (W alone), the NEXT step's A fragments requested into the other register
@@ -470,50 +502,67 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
       step(std::integral_constant<int, 0>{}, acc1, rg_lds + ks * STAGE, rg_lds + (ks + 1) * STAGE, ks > 0 || c > 0);
       step(std::integral_constant<int, 1>{}, acc1, rg_lds + (ks + 1) * STAGE, ks + 2 < KS ? rg_lds + (ks + 2) * STAGE : nullptr, true);
     }
+    stamp();      // 4 + 3 c: phase 1 done
+    if constexpr (QKV) {
+      // q|k|v's weights are touched HERE, ~30 us ahead of phase C: younger than every W load in flight and followed by a
+      // GELU pass without a counted wait, so they stall nothing (in phase B's epilogue they came too late: its first
+      // fragment loads, issued two steps earlier, were cold misses the epilogue then sat waiting for)
+      if (c == NCH - 1) {
+        asm volatile("" ::"v"(warm));
+        warm = warm_lines(p.Wqf, p.wqf_plane, 6144, 0);      // 1536 x 256 halves = 768 KB per plane
+      }
+    }
     // ---- GELU -> planes, into stage `wave` of H (rowffn_kernel) ----
     if (c > 0) rg_lds_barrier();      // every wave is done reading the previous chunk's H
     {
+      // A lane holds ONE hidden column (k) of rows 4 kq + e: written as it stands that is 2-byte LDS stores (80 per lane and
+      // chunk, two lanes per bank word).  Neighbouring lanes (columns k, k + 1) trade one row of each pair instead -- the
+      // even lane takes row e of both columns, the odd lane row e + 1 -- and store whole dwords: half the LDS instructions.
       unsigned char* const hs = hreg + wave * STAGE;
       const int key = (kq & 1) << 1;
+      const int odd = r16 & 1;
+      // v_perm_b32 selectors (bytes of {hi operand, lo operand} = {partner, mine}): even: (mine.lo16 | partner.lo16 << 16),
+      // odd: (partner.hi16 | mine.hi16 << 16)
+      const unsigned sel = odd ? 0x03020706u : 0x05040100u;
 #pragma unroll
       for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const int slot = (2 * nt + (r16 >> 3)) ^ key;
+          float g4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g4[e] = gelu_erf(acc1[mt][nt][e] * csl[nt] + bl[nt]) * p.h_scale;
 #pragma unroll
           for (int e = 0; e < 4; e += 2) {
-            const jv_pk2 gg2 = gelu_erf2(jv_pk2{acc1[mt][nt][e], acc1[mt][nt][e + 1]} * csl[nt] + bl[nt]) * p.h_scale;
-            const Split2 sp = split2h_pair(gg2[0], gg2[1]);
-            const int row = mt * 16 + kq * 4 + e;
-            unsigned char* d = hs + row * 64 + (slot << 4) + (r16 & 7) * 2;
-            *reinterpret_cast<unsigned short*>(d) = (unsigned short)(sp.h & 0xffffu);
-            *reinterpret_cast<unsigned short*>(d + 64) = (unsigned short)(sp.h >> 16);
-            *reinterpret_cast<unsigned short*>(d + A_PLANE) = (unsigned short)(sp.l & 0xffffu);
-            *reinterpret_cast<unsigned short*>(d + A_PLANE + 64) = (unsigned short)(sp.l >> 16);
+            const Split2 sp = split2h_pair(g4[e], g4[e + 1]);      // (row e | row e + 1 << 16) of this lane's column
+            const unsigned ph = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sp.h, 0xB1, 0xf, 0xf, true);      // the neighbour's
+            const unsigned pl = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sp.l, 0xB1, 0xf, 0xf, true);
+            const unsigned wh = __builtin_amdgcn_perm(ph, sp.h, sel), wl = __builtin_amdgcn_perm(pl, sp.l, sel);
+            const int row = mt * 16 + kq * 4 + e + odd;
+            unsigned char* d = hs + row * 64 + (slot << 4) + (r16 & 6) * 2;
+            *reinterpret_cast<unsigned*>(d) = wh;
+            *reinterpret_cast<unsigned*>(d + A_PLANE) = wl;
           }
         }
     }
     rg_lds_barrier();      // H complete
+    stamp();      // 5 + 3 c: GELU done
 #pragma unroll 1
     for (int ks = 0; ks < KS; ks += 2) {
       step(std::integral_constant<int, 0>{}, acc2, hreg + ks * STAGE, hreg + (ks + 1) * STAGE, ks > 0);
       step(std::integral_constant<int, 1>{}, acc2, hreg + (ks + 1) * STAGE,
            ks + 2 < KS ? hreg + (ks + 2) * STAGE : (c + 1 < NCH ? rg_lds : nullptr), true);
     }
+    stamp();      // 6 + 3 c: phase 2 done
   }
+  xstamp();      // B0: loop done
   rg_wait_vmcnt<2>();      // what the next step's middle needs (if there is one), ahead of the epilogue's own memory operations
+  xstamp();      // B1: fragments of the next steps landed
 
   // ---- phase B's epilogue: out = h + ... (+ tracking); QKV: x' = LayerNorm1_next(out) -> X ----
   {
     asm volatile("" ::"v"(warm));
-    if constexpr (QKV) {
-      warm = warm_lines(p.Wqf, p.wqf_plane, 6144, 0);      // 1536 x 256 halves = 768 KB per plane
-    }
-    rg_f32x4 rpre[NRW];
-    const RowFacts facts = row_facts(p.amax_out);
-    prefetch_rows(p.h, p.ldh, rpre);
     rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.cs2 + 4 * lane);
-    cs4 = cs4 * (1.0f / p.h_scale);
     rg_f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (p.b2) b4 = *reinterpret_cast<const rg_f32x4*>(p.b2 + 4 * lane);
     rg_f32x4 gg = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
@@ -521,12 +570,20 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
       gg = *reinterpret_cast<const rg_f32x4*>(p.ln1_g + 4 * lane);
       bb = *reinterpret_cast<const rg_f32x4*>(p.ln1_b + 4 * lane);
     }
+    cs4 = cs4 * (1.0f / p.h_scale);
+    rg_f32x4 rpre[NRW];
+    prefetch_rows(p.h, p.ldh, rpre);
+    xstamp();      // 22: loads requested
     rg_lds_barrier();      // every wave is done with X and H
+    xstamp();      // 23
     acc_to_slab(acc2);
     rg_lds_barrier();
-    row_pass(cs4, b4, rpre, facts, p.out, p.ldo, p.amax_out, QKV, gg, bb, QKV ? p.a_scale_q : 1.f);
+    xstamp();      // 24: slab written
+    row_pass(cs4, b4, rpre, facts_o, p.out, p.ldo, p.amax_out, QKV, gg, bb, QKV ? p.a_scale_q : 1.f);
+    xstamp();      // 25: row pass done
     if constexpr (QKV) rg_lds_barrier();      // X is complete, the slab has been read: the patches go over it
   }
+  stamp();      // 16: epilogue B done
 
   // ================================ phase C: q | k | v of the next block (rowgemm_wa_kernel's loop) ================================
   if constexpr (QKV) {
@@ -546,6 +603,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
         // (the last step of a chunk requests stage 0 again: the next chunk's first step)
         step(std::integral_constant<int, 1>{}, acc1, nullptr, ks + 2 < KS ? rg_lds + (ks + 2) * STAGE : (c + 1 < NCQ ? rg_lds : nullptr), true);
       }
+      stamp();      // 17 + 2 c: chunk loop done
       if (c + 1 < NCQ) {
         rg_wait_vmcnt<2>();
         waited = true;
@@ -578,6 +636,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
           }
         }
       }
+      stamp();      // 18 + 2 c: chunk epilogue done
     }
   }
   // the wrapped-around W loads of the last two steps: bq stays reserved until they have landed (rowgemm_wd_kernel)
@@ -585,6 +644,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
   landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
   asm volatile("" ::"v"(warm));
+  stamp();      // last: drained
 }
 
 }  // namespace jv

@@ -559,31 +559,38 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int e = 0; e < 4; ++e) slab[(mt * 16 + kq * 4 + e) * RG_SLD + wave * 32 + nt * 16 + r16] = acc[mt][nt][e];
-  rg_lds_barrier();
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    constexpr int RPW = RT;      // rows per wave and group: the wave owns tile rows 2 RT wave ... 2 RT wave + 2 RT - 1
-    rg_f32x4 v[RPW], r[RPW], rv[RPW];
-    long mrow[RPW];
-    bool ok[RPW], keep[RPW], tracked[RPW];
-    unsigned seen[RPW];
-    int slot[RPW];
+  // The row pass: rows [2 RT wave, + 2 RT) of the tile, RT at a time.  What a group of rows needs from global memory -- the
+  // residual, the time-embedding vector of its utterance, the tracking slot's current maximum -- is requested a group AHEAD:
+  // group 0's in front of the barrier behind the slab writes, group 1's before group 0 is computed (asked for inside the
+  // group, as this pass first did, every group began by sitting out an L2 round trip with nothing to overlap it).
+  constexpr int RPW = RT;
+  struct RowIn { rg_f32x4 r[RPW], rv[RPW]; unsigned seen[RPW]; int slot[RPW]; bool ok[RPW], keep[RPW], tracked[RPW]; float inv[RPW]; };
+  auto request = [&](auto ps_tag, RowIn& in) {
+    constexpr int ps = decltype(ps_tag)::value;
 #pragma unroll
     for (int jj = 0; jj < RPW; ++jj) {
       const int trow = wave * 2 * RT + ps * RT + jj;
-      mrow[jj] = (long)m0 + trow;
-      ok[jj] = mrow[jj] < p.M;
+      const long mrow = (long)m0 + trow;
+      in.ok[jj] = mrow < p.M;
       const int2 ri = rowinfo[trow];
-      slot[jj] = ri.y & (RI_KEEP - 1);
-      const float inv = ok[jj] ? __uint_as_float((unsigned)ri.x) : 0.f;      // 1 / the power of two its window rows were staged with
-      v[jj] = *reinterpret_cast<const rg_f32x4*>(slab + trow * RG_SLD + 4 * lane) * (cs4 * inv) + b4;
-      keep[jj] = ok[jj] && (ri.y & RI_KEEP) != 0;
-      r[jj] = (p.res && ok[jj]) ? *reinterpret_cast<const rg_f32x4*>(p.res + mrow[jj] * p.ldr + 4 * lane) : rg_f32x4{0.f, 0.f, 0.f, 0.f};
-      rv[jj] = (p.rowvec && ok[jj]) ? *reinterpret_cast<const rg_f32x4*>(p.rowvec + (long)slot[jj] * p.rowvec_ld + 4 * lane)
-                                    : rg_f32x4{0.f, 0.f, 0.f, 0.f};
-      tracked[jj] = ok[jj] && (ri.y & RI_TRACK) != 0;
-      seen[jj] = 0xffffffffu;
-      if (tracked[jj]) seen[jj] = *reinterpret_cast<const unsigned*>(p.amax_out + slot[jj]);
+      in.slot[jj] = ri.y & (RI_KEEP - 1);
+      in.inv[jj] = in.ok[jj] ? __uint_as_float((unsigned)ri.x) : 0.f;      // 1 / the power of two its window rows were staged with
+      in.keep[jj] = in.ok[jj] && (ri.y & RI_KEEP) != 0;
+      in.r[jj] = (p.res && in.ok[jj]) ? *reinterpret_cast<const rg_f32x4*>(p.res + mrow * p.ldr + 4 * lane) : rg_f32x4{0.f, 0.f, 0.f, 0.f};
+      in.rv[jj] = (p.rowvec && in.ok[jj]) ? *reinterpret_cast<const rg_f32x4*>(p.rowvec + (long)in.slot[jj] * p.rowvec_ld + 4 * lane)
+                                          : rg_f32x4{0.f, 0.f, 0.f, 0.f};
+      in.tracked[jj] = in.ok[jj] && (ri.y & RI_TRACK) != 0;
+      in.seen[jj] = 0xffffffffu;
+      if (in.tracked[jj]) in.seen[jj] = *reinterpret_cast<const unsigned*>(p.amax_out + in.slot[jj]);
+    }
+  };
+  auto rows = [&](auto ps_tag, const RowIn& in) {
+    constexpr int ps = decltype(ps_tag)::value;
+    rg_f32x4 v[RPW];
+#pragma unroll
+    for (int jj = 0; jj < RPW; ++jj) {
+      const int trow = wave * 2 * RT + ps * RT + jj;
+      v[jj] = *reinterpret_cast<const rg_f32x4*>(slab + trow * RG_SLD + 4 * lane) * (cs4 * in.inv[jj]) + b4;
     }
     if (p.ln) {
       float sum[RPW], sq[RPW];
@@ -594,19 +601,25 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
         const rg_f32x4 d = v[jj] - sum[jj] * (1.f / 256.f);
         sq[jj] = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
       }
+      // 1 / sqrt(var + eps) of the group's rows in ONE evaluation, lane jj computing row jj's (rowblock_kernel.h)
+      float var_l = sq[0];
+#pragma unroll
+      for (int jj = 1; jj < RPW; ++jj) var_l = lane == jj ? sq[jj] : var_l;
+      const float rstd_l = 1.0f / sqrtf(var_l * (1.f / 256.f) + p.ln_eps);
 #pragma unroll
       for (int jj = 0; jj < RPW; ++jj) {
         const float mean = sum[jj] * (1.f / 256.f);
-        const float rstd = 1.0f / sqrtf(sq[jj] * (1.f / 256.f) + p.ln_eps);
+        const float rstd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rstd_l), jj));
         v[jj] = (v[jj] - mean) * rstd * gg + bb;
       }
     }
 #pragma unroll
     for (int jj = 0; jj < RPW; ++jj) {
+      const long mrow = (long)m0 + wave * 2 * RT + ps * RT + jj;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[jj][e] = keep[jj] ? (mish ? mish_fast(v[jj][e]) : act_apply(v[jj][e], p.act)) : 0.f;
-      v[jj] = (v[jj] + rv[jj]) + r[jj];
-      if (ok[jj]) *reinterpret_cast<rg_f32x4*>(p.out + mrow[jj] * p.ldo + 4 * lane) = v[jj];
+      for (int e = 0; e < 4; ++e) v[jj][e] = in.keep[jj] ? (mish ? mish_fast(v[jj][e]) : act_apply(v[jj][e], p.act)) : 0.f;
+      v[jj] = (v[jj] + in.rv[jj]) + in.r[jj];
+      if (in.ok[jj]) *reinterpret_cast<rg_f32x4*>(p.out + mrow * p.ldo + 4 * lane) = v[jj];
     }
     if (p.amax_out) {
 #pragma unroll
@@ -614,13 +627,21 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
         unsigned u = 0u;
 #pragma unroll
         for (int e = 0; e < 4; ++e) u = max(u, __float_as_uint(v[jj][e]) & 0x7fffffffu);
-        if (tracked[jj] && __builtin_amdgcn_ballot_w64(u > seen[jj]) != 0) {
+        if (in.tracked[jj] && __builtin_amdgcn_ballot_w64(u > in.seen[jj]) != 0) {
 #pragma unroll
           for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o));
-          if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(p.amax_out + slot[jj]), u);
+          if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(p.amax_out + in.slot[jj]), u);
         }
       }
     }
+  };
+  {
+    RowIn in0, in1;
+    request(std::integral_constant<int, 0>{}, in0);      // (rowinfo was written by this workgroup's threads ahead of the main loop's barriers)
+    rg_lds_barrier();
+    request(std::integral_constant<int, 1>{}, in1);
+    rows(std::integral_constant<int, 0>{}, in0);
+    rows(std::integral_constant<int, 1>{}, in1);
   }
   rg_wait_vmcnt<0>();      // the wrapped-around W loads: bq stays reserved until they have landed (rowgemm_wd_kernel)
   landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);

@@ -1279,8 +1279,9 @@ __global__ __launch_bounds__(512, 2) void rowffn_kernel(const RowFfnArgs p) {
           const int slot = (2 * nt + (r16 >> 3)) ^ key;
 #pragma unroll
           for (int e = 0; e < 4; e += 2) {
-            const jv_pk2 gg2 = gelu_erf2(jv_pk2{acc1[mt][nt][e], acc1[mt][nt][e + 1]} * csl[nt] + bl[nt]) * p.h_scale;
-            const Split2 sp = split2h_pair(gg2[0], gg2[1]);
+            const float g0 = gelu_erf(acc1[mt][nt][e] * csl[nt] + bl[nt]) * p.h_scale;
+            const float g1 = gelu_erf(acc1[mt][nt][e + 1] * csl[nt] + bl[nt]) * p.h_scale;
+            const Split2 sp = split2h_pair(g0, g1);
             const int row = mt * 16 + kq * 4 + e;
             unsigned char* d = hs + row * 64 + (slot << 4) + (r16 & 7) * 2;
             *reinterpret_cast<unsigned short*>(d) = (unsigned short)(sp.h & 0xffffu);

@@ -559,6 +559,44 @@ def test_attention_planes(dev, B, L, lens):
         assert torch.equal(op_attention_planes(qkv.to(dev), lens_t.to(dev), B, G, S, L, bounds), first), i
 
 
+@pytest.mark.parametrize("B,L,lens", [(2, 300, [300, 217]), (3, 70, [70, 1, 33]), (1, 512, [512]), (2, 40, [40, 40]),
+                                      (2, 129, [129, 64]), (2, 330, [330, 321]), (1, 1100, [1093])])
+@pytest.mark.parametrize("qt", [None, "2", "3"])
+def test_attention_rows(dev, monkeypatch, B, L, lens, qt):
+    """attention_r.hip (one workgroup per head and 64 QT queries, a wave's K / V^T fragments used for QT 16-query tiles,
+    v_mfma_f32_16x16x32_f16, per-lane row sums) against fp64: its own choice of QT and forced smaller ones (several
+    workgroups per head, idle waves), ragged key masks incl. a last key tile that straddles the mask, fp32 and fp16-plane
+    output; identical bits over repeated launches beside a streaming writer (the DMA ring)"""
+    from jyutvoice_amd.engine import op_attention_planes
+    monkeypatch.setenv("JV_OP_ATTN_ROWS", "1")
+    if qt:
+        monkeypatch.setenv("JV_ATTN_QT", qt)
+    g = torch.Generator().manual_seed(B * 1000 + L + 17)
+    G, gap = 4, 4
+    S = L + gap
+    rows = G + B * S + 8
+    qkv = torch.randn(rows, 1536, generator=g)
+    qkv[:, 512:1024] *= 3.0
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    bounds = tuple(4.0 * float(qkv[:, o:o + 512].abs().max()) for o in (0, 512, 1024))
+    out = op_attention_planes(qkv.to(dev), lens_t.to(dev), B, G, S, L, bounds).cpu()
+    pl = op_attention_planes(qkv.to(dev), lens_t.to(dev), B, G, S, L, bounds, planes_out=True).cpu()
+    for b in range(B):
+        blk = qkv[G + b * S: G + b * S + L].double()
+        q, k, v = (blk[:, i * 512:(i + 1) * 512].view(L, 8, 64).transpose(0, 1) for i in range(3))
+        s = q @ k.transpose(1, 2) / 8.0
+        s[:, :, lens[b]:] = -1e10
+        want = (torch.softmax(s, -1) @ v).transpose(0, 1).reshape(L, 512)
+        sl = slice(G + b * S, G + b * S + L)
+        assert float((out[sl].double() - want).abs().max()) < 5e-6, b
+        assert float((pl[sl] - want).abs().max()) < 5e-6, b
+    first = op_attention_planes(qkv.to(dev), lens_t.to(dev), B, G, S, L, bounds)
+    noise = torch.empty(64 << 20, device=dev)
+    for i in range(6):
+        noise.normal_()
+        assert torch.equal(op_attention_planes(qkv.to(dev), lens_t.to(dev), B, G, S, L, bounds), first), i
+
+
 @pytest.mark.parametrize("rt", ["2", "3", "5"])
 @pytest.mark.parametrize("cin", [256, 512, 64])
 def test_rowconv(dev, monkeypatch, rt, cin):
