@@ -202,6 +202,13 @@ int jv_op_rowgemm(const float* A, int64_t rows, int M, int K, const float* W, in
  * out2 != NULL: result as fp16 planes [2][rows][512] of value * out2_scale, else fp32 rows in out [rows,512]. */
 int jv_op_attention_planes(const float* qkv, int64_t rows, const int32_t* lens, int B, int G, int S, int L, float q_bound,
                            float k_bound, float v_bound, int chunk, float out2_scale, float* out, uint16_t* out2, void* stream);
+/* jv_op_hiftconv: the vocoder's ResBlock convolution (hiftconv_kernel.h; jyutvoice/hifigan/generator.py:90-97):
+ * out = ((Conv1d(C, C, ntaps, dilation dil, same padding)(Snake_alpha(A)) + bias) + res1 + res2) * out_scale (+ out when
+ * accumulate) on a [rows, C] row buffer, C = 64 / 128 / 256, W [C][ntaps * C] tap-major, rows with rowmask == 0 read as zero;
+ * amax_in: one device float >= max |A|, a_extra: max 1 / (alpha + 1e-9); amax_out (optional): max |out| is folded into it. */
+int jv_op_hiftconv(const float* A, int64_t rows, int C, int ntaps, int dil, const float* W, const float* bias, const float* alpha,
+                   const uint8_t* rowmask, const float* res1, const float* res2, float out_scale, int accumulate,
+                   const float* amax_in, float a_extra, float* amax_out, float* out, void* stream);
 /* jv_op_rowconv: the estimator's causal k = 3 convolution to 256 channels at chip-filling batch sizes (rowconv_kernel.h):
  * out[m] = tail(sum_j A[m - 2 + j] W_j + bias), tail = LayerNorm_256 (ln_g != NULL) -> act -> rows with rowmask == 0 := 0 ->
  * + rowvec (one [256] vector here) -> + res; A's fp16x3 scale comes from *amax_in (>= max |A|), amax_out receives max |out|

@@ -68,6 +68,7 @@ SIGNATURES = {
     "jv_op_attention_h3": (_i, [_p, _p, _i, _i, _i, _i, _f, _f, _f, _p, _p]),
     "jv_op_linear_h3": (_i, [_p, _i64, _i, _i, _p, _i, _p, _i, _p, _f, _i, _p, _p]),
     "jv_op_attention_planes": (_i, [_p, _i64, _p, _i, _i, _i, _i, _f, _f, _f, _i, _f, _p, _p, _p]),
+    "jv_op_hiftconv": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _i, _p, _f, _p, _p, _p]),
     "jv_op_rowconv": (_i, [_p, _i64, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
     "jv_op_rowgemm": (_i, [_p, _i64, _i, _i, _p, _i, _p, _i, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p]),
     "jv_op_layernorm": (_i, [_p, _p, _p, _f, _i64, _i, _p, _p]),

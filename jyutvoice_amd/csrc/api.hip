@@ -7,10 +7,12 @@
 #include "../../include/jyutvoice_hip.h"
 #include "jv_model.h"
 #include "jv_ops.h"
+#include "hiftconv_kernel.h"
 #include "rowconv_kernel.h"
 
 namespace jv {
 
+int hiftconv(const HiftConvArgs& a, int C, hipStream_t st);   // hiftconv.hip
 int rowgemm(const RowGemmArgs& a, int epi, hipStream_t st);   // rowgemm.hip
 int rowconv(const RowConvArgs& a, hipStream_t st);
 
@@ -105,6 +107,7 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   c.no_ffn_fuse = getenv("JV_NO_FFN_FUSE") != nullptr;
   c.no_block_fuse = getenv("JV_NO_BLOCK_FUSE") != nullptr;
   c.no_attn_planes = getenv("JV_NO_ATTN_PLANES") != nullptr;
+  c.no_hiftconv = getenv("JV_NO_HIFTCONV") != nullptr;
   c.attn_rows = getenv("JV_ATTN_ROWS") != nullptr;
   c.max_frames = max_frames;
   c.max_tokens = max_tokens;
@@ -503,6 +506,37 @@ int jv_op_rowconv(const float* A, int64_t rows, int M, int Cin, const float* W, 
   a.act = act; a.rowmask_out = rowmask; a.rowvec = rowvec; a.rowvec_ld = N; a.res = res; a.ldr = N;
   a.amax_out = amax_out; a.row_mask = rowmask;
   return jv::rowconv(a, st);
+}
+
+// hiftconv (hiftconv_kernel.h): out = ((Conv1d_k,dil(Snake_alpha(A)) + bias) + res1 + res2) * out_scale (+ out when accumulate) on a
+// [rows, C] row buffer, C = 64 / 128 / 256; W [C][ntaps * C] tap-major; amax_in / amax_out: one slot (test hook)
+int jv_op_hiftconv(const float* A, int64_t rows, int C, int ntaps, int dil, const float* W, const float* bias, const float* alpha,
+                   const uint8_t* rowmask, const float* res1, const float* res2, float out_scale, int accumulate,
+                   const float* amax_in, float a_extra, float* amax_out, float* out, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int K = ntaps * C;
+  static void* scratch = nullptr;
+  static size_t cap = 0;
+  const size_t n = (size_t)C * K;
+  const size_t head = ((n * 4 + (size_t)C * 12 + 256) + 255) & ~(size_t)255;
+  const size_t need = head + n * 4;
+  if (need > cap) {
+    if (scratch) (void)hipFree(scratch);
+    JV_HIP(hipMalloc(&scratch, need));
+    cap = need;
+  }
+  unsigned short* planes = static_cast<unsigned short*>(scratch);
+  float* cs = reinterpret_cast<float*>(static_cast<char*>(scratch) + ((n * 4 + 63) & ~(size_t)63));
+  unsigned short* wf = reinterpret_cast<unsigned short*>(static_cast<char*>(scratch) + head);
+  JV_TRY(jv::split2h_planes(W, C, K, cs + C, planes, cs, st));
+  JV_TRY(jv::pack_wfrag(planes, (long)n, K, C, K, wf, (long)n, st));
+  jv::HiftConvArgs a{};
+  a.A = A; a.a_rows = rows; a.M = (int)rows; a.ntaps = ntaps; a.dil = dil; a.tap_row0 = -(dil * (ntaps - 1) / 2); a.rowmask_in = rowmask;
+  a.alpha = alpha; a.Wf = wf; a.wf_plane = (long)n; a.colscale = cs; a.bias = bias;
+  a.amax_in = amax_in; a.a_extra = a_extra; a.slot_G = 0; a.slot_S = 0; a.slot_nb = 1;
+  a.out = out; a.res1 = res1; a.res2 = res2; a.out_scale = out_scale; a.accumulate = accumulate;
+  a.amax_out = amax_out; a.amax_mask = rowmask;
+  return jv::hiftconv(a, C, st);
 }
 
 // attention64_planes (attention_pl.hip) on an fp32 qkv matrix: K and V are split into planes here the way the qkv GEMM's

@@ -45,6 +45,7 @@ struct FlowWs {
   int amax_stride = 0;      // floats per buffer = 2 * max_batch
   float* partial = nullptr;      // [8][PARTIAL_ROWS][256] split-K partial sums (short M only)
   unsigned long long* rb_stamps = nullptr;      // tuning builds, JV_RB_STAMPS: rowblock_kernel's phase stamps of the last launch
+  unsigned long long* rc_stamps = nullptr;      // ... and rowconv_wd_kernel's
   float *d = nullptr;                                                 // [rows,80]
   float *tsin = nullptr, *t1 = nullptr, *tmish = nullptr, *temb = nullptr;
   float *t_dev = nullptr, *t_table = nullptr, *dt_table = nullptr;
@@ -245,11 +246,17 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     r.W2 = m.w2; r.w2_plane = (long)m.n_rows * m.ldw; r.ldw = m.ldw; r.colscale = m.colscale;
     r.Wf = m.wf; r.wf_plane = (long)m.N * m.ntaps * m.Cin;
     r.amax_in = a.amax_in; r.row_slot = w.row_sample; r.bias = a.bias;
+    r.slot_G = FLOW_G; r.slot_S = g.S; r.slot_nb = B2;      // = row_sample, by arithmetic (row_meta lays utterance b at G + b S)
     r.out = a.out; r.ldo = a.ldo;
     r.ln = a.ln; r.ln_g = a.ln_g; r.ln_b = a.ln_b; r.ln_eps = a.ln_eps; r.act = a.act; r.rowmask_out = a.rowmask_out;
     r.rowvec = a.rowvec; r.rowvec_ld = a.rowvec_ld; r.res = a.res1; r.ldr = a.ldr1;
     r.amax_out = a.amax_out; r.row_mask = w.rowmask;
     r.alg_rows = a.alg_rows;
+    if (tuning_env("JV_RB_STAMPS")) {
+      if (!w.rc_stamps) JV_TRY(ws_alloc(c, 1024 * 8 * sizeof(unsigned long long), reinterpret_cast<void**>(&w.rc_stamps)));
+      r.stamps = w.rc_stamps;
+      JV_HIP(hipMemsetAsync(r.stamps, 0, 1024 * 8 * sizeof(unsigned long long), st));
+    }
     return rowconv(r, st);
   };
   // CausalResnetBlock1D (decoder.py:110-115, 784-795)
@@ -412,9 +419,9 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
       // to_out -> LayerNorm3 -> feed-forward (-> the next block's LayerNorm1 -> q | k | v) in ONE launch on the same rows: the
       // LayerNorm planes never leave LDS (rowblock_kernel.h)
       RowBlockArgs f{};
-      f.A2 = reinterpret_cast<const unsigned short*>(w.att); f.a2_plane = R * 512; f.a_rows = g.a_rows; f.lda2 = 512; f.M = (int)g.M;
+      f.A2 = reinterpret_cast<const unsigned short*>(w.att); f.a2_plane = R * 512; f.a_rows = g.a_rows; f.M = (int)g.M;
       f.Wof = b.out.wf; f.wof_plane = (long)b.out.N * b.out.Cin; f.cso = b.out.colscale; f.bo = b.out.bias; f.a_scale_o = b.out.a_scale;
-      f.h = h; f.ldh = 256; f.ln3_g = b.n3.g; f.ln3_b = b.n3.b; f.ln_eps = 1e-5f;
+      f.h = h; f.ln3_g = b.n3.g; f.ln3_b = b.n3.b;
       f.W1f = b.ff1.wf; f.w1f_plane = (long)b.ff1.N * b.ff1.Cin; f.cs1 = b.ff1.colscale; f.b1 = b.ff1.bias; f.a_scale1 = b.ff1.a_scale;
       f.h_scale = b.ff2.a_scale;
       f.W2f = b.ff2.wf; f.w2f_plane = (long)b.ff2.N * b.ff2.Cin; f.cs2 = b.ff2.colscale; f.b2 = b.ff2.bias;
@@ -425,12 +432,13 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
       if (qkv) {
         f.ln1_g = next->n1.g; f.ln1_b = next->n1.b;
         f.Wqf = next->qkv.wf; f.wqf_plane = (long)next->qkv.N * next->qkv.Cin; f.csq = next->qkv.colscale; f.a_scale_q = next->qkv.a_scale;
-        f.q = w.qkv; f.ldq = 512; f.kv2 = kv2; f.kv2_plane = R * 1024; f.ldkv = 1024; f.k_scale = next->k_scale; f.v_scale = next->v_scale;
+        f.q = w.qkv; f.kv2 = kv2; f.kv2_plane = R * 1024; f.k_scale = next->k_scale; f.v_scale = next->v_scale;
       }
       *qkv_next = qkv;
       if (tuning_env("JV_RB_STAMPS")) {
         if (!w.rb_stamps) JV_TRY(ws_alloc(c, 2 * 1024 * 48 * sizeof(unsigned long long), reinterpret_cast<void**>(&w.rb_stamps)));
         f.stamps = w.rb_stamps + (qkv ? 0 : 1024 * 48);
+        JV_HIP(hipMemsetAsync(f.stamps, 0, 1024 * 48 * sizeof(unsigned long long), st));      // the stamps are atomic maxima
       }
       return rowblock(f, qkv, st);
     }
@@ -695,6 +703,20 @@ int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spk
         std::vector<long> d;
         for (int b = 0; b < nwg; ++b)
           if (hs[(size_t)b * 48 + i] > hs[(size_t)b * 48]) d.push_back((long)(hs[(size_t)b * 48 + i] - hs[(size_t)b * 48]));
+        if (d.empty()) continue;
+        std::sort(d.begin(), d.end());
+        fprintf(stderr, " %d:%ld", i, d[d.size() / 2]);
+      }
+      fprintf(stderr, "\n");
+    }
+    if (w.rc_stamps) {
+      std::vector<unsigned long long> hc((size_t)nwg * 8);
+      JV_HIP(hipMemcpy(hc.data(), w.rc_stamps, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[rowconv stamps] %d workgroups; median cycles since start:", nwg);
+      for (int i = 1; i < 8; ++i) {
+        std::vector<long> d;
+        for (int b = 0; b < nwg; ++b)
+          if (hc[(size_t)b * 8 + i] > hc[(size_t)b * 8]) d.push_back((long)(hc[(size_t)b * 8 + i] - hc[(size_t)b * 8]));
         if (d.empty()) continue;
         std::sort(d.begin(), d.end());
         fprintf(stderr, " %d:%ld", i, d[d.size() / 2]);

@@ -10,10 +10,13 @@
 // the gaps (>= 25 rows at every level) are the zero padding of every dilated ResBlock convolution.
 // Snake / LeakyReLU run in the conv kernel's prologue, bias / residual / x+si fusion / MRF mean in its epilogue.
 #include "../../include/jyutvoice_hip.h"
+#include "hiftconv_kernel.h"
 #include "jv_model.h"
 #include "jv_ops.h"
 
 namespace jv {
+
+int hiftconv(const HiftConvArgs& a, int C, hipStream_t st);      // hiftconv.hip
 
 int f0_head(const float* h, const float* w, const float* bias, float* f0, int B, int T, int G, int S, hipStream_t st);
 int sine_source(const float* f0, const float* phase, const float* noise, const float* lin_w, const float* lin_b, float* frac,
@@ -166,11 +169,31 @@ void h3_measured(ConvGemmArgs& a, const GemmW& w, const float* am_in, float extr
 // am_*: the amax slots of cur, r, tmp and dst (HiftWs::amax); h3: fp16x3 allowed (not exact-range mode)
 int resblock(const ResBlockW& rb, const HGeo& g, int lvl, int C, long rows, long alloc, const unsigned char* mask, const float* cur,
              float* r, float* tmp, float* dst, const float* extra_res, float scale, int accumulate, float* am_cur, float* am_r,
-             float* am_tmp, float* am_dst, bool h3, hipStream_t st) {
+             float* am_tmp, float* am_dst, bool h3, bool rowconv, hipStream_t st) {
   const int dils[3] = {1, 3, 5};
   const float* in = cur;
+  // the row-owning form (hiftconv_kernel.h): the whole Snake'd window in LDS, weights in fragment order
+  auto rc = [&](const GemmW& w, const float* A, const float* alpha, float extra, float* am_in, int tap_row0, int dil, float* out,
+                const float* res1, const float* res2, float out_scale, int acc, float* am_out) -> int {
+    HiftConvArgs a{};
+    a.A = A; a.a_rows = alloc; a.M = (int)rows; a.ntaps = w.ntaps; a.dil = dil; a.tap_row0 = tap_row0; a.rowmask_in = mask;
+    a.alpha = alpha; a.Wf = w.wf; a.wf_plane = (long)w.N * w.ntaps * w.Cin; a.colscale = w.colscale; a.bias = w.bias;
+    a.amax_in = am_in; a.a_extra = extra; a.slot_G = g.G[lvl]; a.slot_S = g.S[lvl]; a.slot_nb = g.B;
+    a.out = out; a.res1 = res1; a.res2 = res2; a.out_scale = out_scale; a.accumulate = acc;
+    a.amax_out = am_out; a.amax_mask = mask;
+    a.alg_rows = (long)g.B * g.L[lvl];
+    return hiftconv(a, C, st);
+  };
   for (int j = 0; j < 3; ++j) {
     const int k = rb.k, d = dils[j];
+    if (rowconv && h3 && rb.c1[j].wf && rb.c2[j].wf && rb.e1[j] > 0.f && rb.e2[j] > 0.f) {
+      const bool last = j == 2;
+      JV_TRY(rc(rb.c1[j], in, rb.a1[j], rb.e1[j], j == 0 ? am_cur : am_r, -(d * (k - 1) / 2), d, tmp, nullptr, nullptr, 1.f, 0, am_tmp));
+      JV_TRY(rc(rb.c2[j], tmp, rb.a2[j], rb.e2[j], am_tmp, -((k - 1) / 2), 1, last ? dst : r, in, last ? extra_res : nullptr,
+                last ? scale : 1.f, last ? accumulate : 0, last ? am_dst : am_r));
+      in = r;
+      continue;
+    }
     ConvGemmArgs a = conv_args(in, C, alloc, rows, rb.c1[j], tmp, C, -(d * (k - 1) / 2), d, mask);
     a.pro = PRO_SNAKE; a.pro_alpha = rb.a1[j];
     h3_measured(a, rb.c1[j], j == 0 ? am_cur : am_r, rb.e1[j], h3 && rb.e1[j] > 0.f);
@@ -265,13 +288,13 @@ int hift_decode(Context& c, const float* mel, const float* s, const int* lens, i
       amax_geo(a, g, l, w.mask[l]);
       JV_TRY(conv_gemm(a, 1, st));
       JV_TRY(resblock(h.src_rb[i], g, l, C, g.rows[l], g.alloc[l], w.mask[l], w.si[i], w.r[i], w.tmp[i], w.xs[i], w.x[i], 1.f, 0,
-                      am(HiftWs::A_SI + i), am(HiftWs::A_R + i), am(HiftWs::A_TMP + i), am(HiftWs::A_XS + i), h3, st));
+                      am(HiftWs::A_SI + i), am(HiftWs::A_R + i), am(HiftWs::A_TMP + i), am(HiftWs::A_XS + i), h3, !c.no_hiftconv, st));
     }
     // x = xs now holds x_up + si ; MRF: mean of the three ResBlocks, accumulated into w.x[i]
     for (int j = 0; j < 3; ++j)
       JV_TRY(resblock(h.rb[3 * i + j], g, l, C, g.rows[l], g.alloc[l], w.mask[l], w.xs[i], w.r[i], w.tmp[i], w.x[i], nullptr,
                       1.f / 3.f, j > 0 ? 1 : 0, am(HiftWs::A_XS + i), am(HiftWs::A_R + i), am(HiftWs::A_TMP + i),
-                      am(HiftWs::A_X + i), h3, st));
+                      am(HiftWs::A_X + i), h3, !c.no_hiftconv, st));
     prev = w.x[i];
     am_prev = am(HiftWs::A_X + i);
     prevC = C;

@@ -136,6 +136,7 @@ struct Context {
   bool rg_ff1 = true;            // ff.net.0 on the row-owning GEMM too; JV_TILE_FF1=1: on the tile kernel (the round-2 first build, for A/B runs)
   bool attn_rows = false;        // JV_ATTN_ROWS=1: the estimator's attention on attention_r.hip (one workgroup per head, 80 queries per wave; measured
                                  // 66.6 us against attention_pl.hip's 60.0 at 32 x 300 frames: kept as a tested alternative)
+  bool no_hiftconv = false;      // JV_NO_HIFTCONV=1: the vocoder's ResBlock convolutions on the tile kernels (A/B aid; the path hiftconv_kernel is checked against)
   bool no_attn_planes = false;   // JV_NO_ATTN_PLANES=1: attention splits K / V itself (attention.hip) instead of taking planes
   bool no_splitk = false;        // JV_NO_SPLITK=1: no split-K at short M (A/B aid)
   bool no_rowgemm = false;       // JV_NO_ROWGEMM=1: keep the transformer linears on the tile kernels at every batch size (A/B aid)

@@ -429,10 +429,13 @@ struct Packer {
     return stats + g.n_rows;
   }
   // ... and a second copy of the planes in fragment order for the row-owning GEMM (rowgemm_kernel.h, W-direct)
-  void wfrag(GemmW& g) {
+  // vocoder = true: the ResBlock convolutions (any tap count, 64 / 128 / 256 channels: hiftconv_kernel.h)
+  void wfrag(GemmW& g, bool vocoder = false) {
     // linears (K = Cin) and the trunk's k = 3 convolutions (K = 3 Cin, tap-major columns: rowconv_wd_kernel)
     const int K = g.ntaps * g.Cin;
-    if (!g.w2 || rc != JV_OK || (g.ntaps != 1 && g.ntaps != 3) || (g.N & 255) || (g.Cin & 63) || g.ldw != K) return;
+    if (!g.w2 || rc != JV_OK || g.ldw != K) return;
+    if (vocoder ? ((g.N != 64 && g.N != 128 && g.N != 256) || g.Cin != g.N || g.n_rows < g.N)
+                : ((g.ntaps != 1 && g.ntaps != 3) || (g.N & 255) || (g.Cin & 63))) return;
     const long n = (long)g.N * K;
     float* d = alloc((size_t)n + 8);
     if (!d) return;
@@ -714,6 +717,7 @@ int finalize_model(Context& c, int model, hipStream_t st) {
         // fp16x3 with a measured input bound (hift.hip): planes + what the Snake prologue can add on top of |x|
         (void)pk.half3(w.c1[j]);
         (void)pk.half3(w.c2[j]);
+        pk.wfrag(w.c1[j], true); pk.wfrag(w.c2[j], true);
         w.e1[j] = pk.snake_extra(w.a1[j], ch);
         w.e2[j] = pk.snake_extra(w.a2[j], ch);
       }

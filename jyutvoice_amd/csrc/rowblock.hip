@@ -45,18 +45,23 @@ int rowblock(const RowBlockArgs& a, bool qkv, hipStream_t st) {
     return fail(JV_ERR_ARG, "rowblock: to_out needs the attention planes, fragment-order weights, scales, h and LayerNorm3");
   if (!a.W1f || !a.W2f || !a.cs1 || !a.cs2 || !(a.a_scale1 > 0.f) || !(a.h_scale > 0.f) || !a.out)
     return fail(JV_ERR_ARG, "rowblock: the feed-forward pair needs both weight matrices in fragment order, their scales and an output");
-  if ((a.lda2 & 7) || (a.ldh & 3) || (a.ldo & 3)) return fail(JV_ERR_ARG, "rowblock: aligned strides required");
-  if (qkv && (!a.Wqf || !a.csq || !(a.a_scale_q > 0.f) || !a.ln1_g || !a.ln1_b || !a.q || !a.kv2 || (a.ldq & 3) || (a.ldkv & 3) ||
-              !(a.k_scale > 0.f) || !(a.v_scale > 0.f)))
+  if (a.ldo & 3) return fail(JV_ERR_ARG, "rowblock: aligned output stride required");
+  if (qkv && (a.out != a.h || a.ldo != 256)) return fail(JV_ERR_ARG, "rowblock: the q|k|v phase follows a block that writes the trunk in place");
+  if (qkv && (!a.Wqf || !a.csq || !(a.a_scale_q > 0.f) || !a.ln1_g || !a.ln1_b || !a.q || !a.kv2 || !(a.k_scale > 0.f) || !(a.v_scale > 0.f)))
     return fail(JV_ERR_ARG, "rowblock: the q|k|v phase needs LayerNorm1, fragment-order weights, scales, a q buffer and a K/V plane buffer");
   int rt = rowgemm_tile(a.M);
   if (rt == 0) rt = 2;
+  if (rt == 1) rt = 2;
+  // the kernel reads whole tiles: rows up to the end of the last one must exist in every row buffer
+  if ((long)cdiv(a.M, 16 * rt) * 16 * rt > a.a_rows) return fail(JV_ERR_ARG, "rowblock: the row buffers must hold whole tiles (a_rows)");
+  RowBlockArgs b = a;      // the reciprocals of the (power-of-two) scales, for the kernel
+  b.inv_a_scale_o = 1.0f / a.a_scale_o; b.inv_a_scale1 = 1.0f / a.a_scale1; b.inv_h_scale = 1.0f / a.h_scale;
+  b.inv_a_scale_q = qkv ? 1.0f / a.a_scale_q : 0.f;
   switch (rt) {
-    case 1:
-    case 2: return rb_launch1<2>(a, qkv, st);
-    case 3: return rb_launch1<3>(a, qkv, st);
-    case 4: return rb_launch1<4>(a, qkv, st);
-    case 5: return rb_launch1<5>(a, qkv, st);
+    case 2: return rb_launch1<2>(b, qkv, st);
+    case 3: return rb_launch1<3>(b, qkv, st);
+    case 4: return rb_launch1<4>(b, qkv, st);
+    case 5: return rb_launch1<5>(b, qkv, st);
     default: return fail(JV_ERR_ARG, "rowblock: bad tile height");
   }
 }

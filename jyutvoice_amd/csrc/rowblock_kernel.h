@@ -32,22 +32,24 @@ namespace jv {
 
 struct RowBlockArgs {
   // ---- phase A: attn1.to_out.0 (N = 256, K = 512) + residual + LayerNorm3
-  const unsigned short* A2;      // attention planes [2][a_rows][lda2] of att * a_scale_o
+  // Every row buffer must be readable up to row ceil(M / tile) * tile - 1 (the host checks a_rows): rows past M - 1 are read
+  // unclamped (their results are never stored or tracked) and the strides are compile-time -- h [., 256], attention planes
+  // [., 512], q [., 512], K/V planes [., 1024] -- so that a row's address is a constant offset from the tile's first row
+  const unsigned short* A2;      // attention planes [2][a_rows][512] of att * a_scale_o
   long a2_plane, a_rows;
-  int lda2, M;
+  int M;
   const unsigned short* Wof;     // fragment order, plane stride wof_plane halves
   long wof_plane;
   const float *cso, *bo;
-  float a_scale_o;
-  float* h;                      // [rows, ldh] fp32: residual in, h + to_out(att) out (in place)
-  long ldh;
+  float a_scale_o, inv_a_scale_o;      // (the reciprocals of the powers of two, from the host: an IEEE division is ten instructions)
+  float* h;                      // [rows, 256] fp32: residual in, h + to_out(att) out (in place)
   const float *ln3_g, *ln3_b;
-  float ln_eps;
   // ---- phase B: ff.net.0 (N = 1024, K = 256) -> GELU -> ff.net.2 (N = 256, K = 1024) + residual
   const unsigned short* W1f;
   long w1f_plane;
   const float *cs1, *b1;
   float a_scale1, h_scale;       // a_scale1: what LayerNorm3's planes are scaled with; h_scale: the hidden planes
+  float inv_a_scale1, inv_h_scale;
   const unsigned short* W2f;
   long w2f_plane;
   const float *cs2, *b2;
@@ -62,12 +64,10 @@ struct RowBlockArgs {
   const unsigned short* Wqf;
   long wqf_plane;
   const float* csq;
-  float a_scale_q;               // what LayerNorm1's planes are scaled with
-  float* q;                      // fp32 rows [., ldq], 512 columns
-  long ldq;
-  unsigned short* kv2;           // planes [2][rows][ldkv]: k * k_scale in columns 0..511, v * v_scale in 512..1023
+  float a_scale_q, inv_a_scale_q;      // what LayerNorm1's planes are scaled with
+  float* q;                      // fp32 rows [., 512]
+  unsigned short* kv2;           // planes [2][rows][1024]: k * k_scale in columns 0..511, v * v_scale in 512..1023
   long kv2_plane;
-  int ldkv;
   float k_scale, v_scale;
   long alg_rows;
   unsigned long long* stamps;      // tuning aid (JV_RB_STAMPS, tuning builds): [workgroup][48] s_memtime at the phase boundaries
@@ -91,8 +91,11 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   constexpr int H_OFF = KS * STAGE;
   constexpr int NSEG = QKV ? 2 + 2 * NCH + NCQ : 2 + 2 * NCH;
   constexpr int NRW = 2 * RT;                    // rows per wave in the row passes
+  constexpr float LN_EPS = 1e-5f;                // nn.LayerNorm's default (transformer.py:355-443 builds its norms with it)
+  constexpr long LDH = 256, LDQ = 512, LDKV = 1024;
   static_assert(8 * STAGE == R * 1024, "the unpadded slab is exactly the upper half of LDS");
-  static_assert(8 * 16 * 36 * 4 <= 8 * STAGE, "the per-wave patches of phase C fit there too");
+  constexpr int NPATCH = 8 * 2 * 16 * 36 * 4 <= 8 * STAGE ? 2 : 1;      // transposition patches per wave in phase C (one at RT = 2)
+  static_assert(8 * NPATCH * 16 * 36 * 4 <= 8 * STAGE, "the per-wave patches of phase C fit the upper half");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kq = lane >> 4;
@@ -101,7 +104,8 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   int stamp_i = 0;
   auto stamp = [&]() {      // (compiled out unless JV_TUNING)
     if (JV_STAMP(p)) {
-      if (tid == 0 && stamp_i < 32) p.stamps[(long)blockIdx.x * 48 + stamp_i] = __builtin_amdgcn_s_memtime();
+      // the LAST wave's arrival (wave 0 alone reads fast: the older wave of a SIMD wins the matrix pipe's arbitration)
+      if (lane == 0 && stamp_i < 32) atomicMax(&p.stamps[(long)blockIdx.x * 48 + stamp_i], (unsigned long long)__builtin_amdgcn_s_memtime());
       ++stamp_i;
     }
   };
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   int xstamp_i = 32;
   auto xstamp = [&]() {      // detail stamps inside the epilogues: slots 32..47
     if (JV_STAMP(p)) {
-      if (tid == 0 && xstamp_i < 48) p.stamps[(long)blockIdx.x * 48 + xstamp_i] = __builtin_amdgcn_s_memtime();
+      if (lane == 0 && xstamp_i < 48) atomicMax(&p.stamps[(long)blockIdx.x * 48 + xstamp_i], (unsigned long long)__builtin_amdgcn_s_memtime());
       ++xstamp_i;
     }
   };
@@ -127,12 +131,16 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
     float v = 0.f;
     if (i < per && l < 2 * lines_per_plane) {
       const int pl = l >= lines_per_plane;
-      v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + (long)pl * plane_halves) + ((l - pl * lines_per_plane) << 7));
+      // (explicitly GLOBAL loads and stores throughout this kernel: through a lambda's pointer parameter the compiler lost the
+      // address space and emitted flat_load / flat_store, which count on lgkmcnt as well -- every LDS wait and every barrier
+      // then also waited for the rows' residual loads and stores in flight)
+      v = *(const __attribute__((address_space(1))) float*)(reinterpret_cast<const char*>(base + (long)pl * plane_halves) + ((l - pl * lines_per_plane) << 7));
     }
     return v;
   };
   float warm = warm_lines(p.Wof, p.wof_plane, 2048, 0);      // 256 x 512 halves = 256 KB per plane
   float warm1 = warm_lines(p.W1f, p.w1f_plane, 4096, 0);     // 1024 x 256 halves = 512 KB per plane
+  float warm2 = 0.f, warm3 = 0.f;
 
   // Per-row facts of the tracking (mask, slot, the slots' current maxima): lane j < NRW loads those of the wave's row j and
   // the row passes broadcast them with v_readlane.  Loaded HERE, at kernel start, where the dependent chain (row -> slot ->
@@ -161,9 +169,8 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
     for (int i = 0; i < PPW; ++i) {
       const int pc = wave + 8 * i;
       const int pl = pc / RT, g = pc % RT;
-      long row = (long)m0 + g * 16 + prow;
-      row = row < p.a_rows ? row : p.a_rows - 1;
-      cur[i] = p.A2 + (long)(pl & 1) * p.a2_plane + row * p.lda2 + 8 * pslot;
+      const long row = (long)m0 + g * 16 + prow;
+      cur[i] = p.A2 + (long)(pl & 1) * p.a2_plane + row * 512 + 8 * pslot;
       dst[i] = (pl & 1) * A_PLANE + g * 1024;
     }
   }
@@ -273,6 +280,10 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   rg_wait_vmcnt<0>();
   landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
   landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
+  // A warm-up value is "used" (an empty asm) where the wait costs nothing and is dead from then on.  Kept alive to the end
+  // of the kernel it crossed the feed-forward loop -- in scratch: the compiler spilled it right behind the load, i.e. put an
+  // s_waitcnt vmcnt(0) on a load that is an L2 miss BY DESIGN in front of phase A's epilogue (6 k cycles in the stamps).
+  asm volatile("" ::"v"(warm), "v"(warm1));
   rg_barrier();
   stamp();      // 1: prologue done
   read_a(std::integral_constant<int, 0>{}, hreg);
@@ -347,14 +358,16 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
       constexpr int ps = decltype(ps_tag)::value;
       rg_f32x4 v[RT];
       bool ok[RT];
+      int drow0 = m0 + wave * NRW + ps * RT;      // (laundered: see prefetch_rows)
+      asm volatile("" : "+s"(drow0));
+      float* const dbase = dstp + (long)drow0 * ldd;
 #pragma unroll
       for (int j = 0; j < RT; ++j) {
         const int trow = wave * NRW + ps * RT + j;
-        const long mrow = (long)m0 + trow;
-        ok[j] = mrow < p.M;
+        ok[j] = m0 + trow < p.M;
         v[j] = *reinterpret_cast<const rg_f32x4*>(slab + rb_slab(trow, 4 * lane)) * cs4 + b4;
         v[j] += rpre[ps * RT + j];
-        if (ok[j]) *reinterpret_cast<rg_f32x4*>(dstp + mrow * ldd + lane4) = v[j];
+        if (ok[j]) *(__attribute__((address_space(1))) rg_f32x4*)(dbase + j * ldd + lane4) = v[j];
       }
       if (amax) {
 #pragma unroll
@@ -385,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
         float var_l = sq[0];
 #pragma unroll
         for (int j = 1; j < RT; ++j) var_l = lane == j ? sq[j] : var_l;
-        const float rstd_l = 1.0f / sqrtf(var_l * (1.f / 256.f) + p.ln_eps);
+        const float rstd_l = 1.0f / sqrtf(var_l * (1.f / 256.f) + LN_EPS);
 #pragma unroll
         for (int j = 0; j < RT; ++j) {
           const int trow = wave * NRW + ps * RT + j;
@@ -404,15 +417,20 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
     rows(std::integral_constant<int, 0>{});
     rows(std::integral_constant<int, 1>{});
   };
-  // the rows' residual values, requested BEFORE the accumulators go through the slab (rowgemm_wd_kernel): a uniform row base
-  // plus an unsigned lane offset -- the scalar-base form of the load, no 64-bit address register pair per row
-  auto prefetch_rows = [&](const float* res, const long ldr, rg_f32x4 (&rpre)[NRW]) {
+  // the rows' residual values, requested BEFORE the accumulators go through the slab (rowgemm_wd_kernel): one base address
+  // and constant row offsets (asked for with a run-time stride and a clamp per row, the ten addresses were 150 scalar
+  // instructions in front of the epilogue's barrier)
+  auto prefetch_rows = [&](const float* res, rg_f32x4 (&rpre)[NRW]) {
+    // The wave's first row, laundered through an SGPR: the two epilogues read the same rows of h, and with a common
+    // subexpression the compiler kept the ten 64-bit lane addresses alive across the feed-forward loop -- in scratch, each
+    // reload followed by s_waitcnt vmcnt(0), i.e. by a wait for the residual loads just issued: six L2 round trips in
+    // series in front of the epilogue (5 k cycles in the phase stamps).  A uniform base + the unsigned lane offset is the
+    // scalar-base form of the load: no address registers at all.
+    int row0 = m0 + wave * NRW;
+    asm volatile("" : "+s"(row0));
+    const float* const base = res + (long)row0 * LDH;
 #pragma unroll
-    for (int j = 0; j < NRW; ++j) {
-      const long mr0 = (long)m0 + wave * NRW + j;
-      const long mr = mr0 < p.M ? mr0 : (long)p.M - 1;
-      rpre[j] = *reinterpret_cast<const rg_f32x4*>(res + mr * ldr + lane4);
-    }
+    for (int j = 0; j < NRW; ++j) rpre[j] = *(const __attribute__((address_space(1))) rg_f32x4*)(base + j * LDH + lane4);
   };
   auto acc_to_slab = [&](const rg_f32x4 (&acc)[RT][2]) {
 #pragma unroll
@@ -425,8 +443,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
 
   // ---- phase A's epilogue: h += ... ; x = LayerNorm3(h) -> X ----
   {
-    asm volatile("" ::"v"(warm), "v"(warm1));                  // (the kernel-start warm-up loads are long done)
-    warm = warm_lines(p.W2f, p.w2f_plane, 4096, 0);            // 256 x 1024 halves = 512 KB per plane
+    warm2 = warm_lines(p.W2f, p.w2f_plane, 4096, 0);           // 256 x 1024 halves = 512 KB per plane
     // (the per-column constants FIRST: vmcnt retires in order, so the first use of one of them must not have the rows'
     // residual loads in front of it -- it then waited for all ten, ~2 us, before the slab pass had even begun)
     rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.cso + 4 * lane);
@@ -434,17 +451,18 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
     if (p.bo) b4 = *reinterpret_cast<const rg_f32x4*>(p.bo + 4 * lane);
     const rg_f32x4 gg = *reinterpret_cast<const rg_f32x4*>(p.ln3_g + 4 * lane);
     const rg_f32x4 bb = *reinterpret_cast<const rg_f32x4*>(p.ln3_b + 4 * lane);
-    cs4 = cs4 * (1.0f / p.a_scale_o);
     rg_f32x4 rpre[NRW];
-    prefetch_rows(p.h, p.ldh, rpre);
+    prefetch_rows(p.h, rpre);
     xstamp();      // 18: loads requested
     rg_lds_barrier();      // every wave is done reading the ring: the slab goes over it
     xstamp();      // 19
     acc_to_slab(acc1);
     rg_lds_barrier();
     xstamp();      // 20: slab written
-    row_pass(cs4, b4, rpre, facts_h, p.h, p.ldh, p.amax_h, true, gg, bb, p.a_scale1);
+    cs4 = cs4 * p.inv_a_scale_o;      // (first use of a loaded value: HERE, behind the barriers that hide the loads' ~2 k cycles, not in front of them)
+    row_pass(cs4, b4, rpre, facts_h, p.h, LDH, p.amax_h, true, gg, bb, p.a_scale1);
     xstamp();      // 21: row pass done (this wave)
+    asm volatile("" ::"v"(warm2));      // (issued a whole row pass ago)
     rg_lds_barrier();      // X is complete, the slab has been read: the upper half is free for H
   }
   stamp();      // 3: epilogue A done
@@ -482,7 +500,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) acc2[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
-  const float inv1 = 1.0f / p.a_scale1;
+  const float inv1 = p.inv_a_scale1;
 #pragma unroll 1
   for (int c = 0; c < NCH; ++c) {
     // ---- the hidden chunk ----
@@ -507,10 +525,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
       // q|k|v's weights are touched HERE, ~30 us ahead of phase C: younger than every W load in flight and followed by a
       // GELU pass without a counted wait, so they stall nothing (in phase B's epilogue they came too late: its first
       // fragment loads, issued two steps earlier, were cold misses the epilogue then sat waiting for)
-      if (c == NCH - 1) {
-        asm volatile("" ::"v"(warm));
-        warm = warm_lines(p.Wqf, p.wqf_plane, 6144, 0);      // 1536 x 256 halves = 768 KB per plane
-      }
+      if (c == NCH - 1) warm3 = warm_lines(p.Wqf, p.wqf_plane, 6144, 0);      // 1536 x 256 halves = 768 KB per plane
     }
     // ---- GELU -> planes, into stage `wave` of H (rowffn_kernel) ----
     if (c > 0) rg_lds_barrier();      // every wave is done reading the previous chunk's H
@@ -558,10 +573,10 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   xstamp();      // B0: loop done
   rg_wait_vmcnt<2>();      // what the next step's middle needs (if there is one), ahead of the epilogue's own memory operations
   xstamp();      // B1: fragments of the next steps landed
+  if constexpr (QKV) asm volatile("" ::"v"(warm3));      // (issued at the last GELU pass)
 
   // ---- phase B's epilogue: out = h + ... (+ tracking); QKV: x' = LayerNorm1_next(out) -> X ----
   {
-    asm volatile("" ::"v"(warm));
     rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.cs2 + 4 * lane);
     rg_f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (p.b2) b4 = *reinterpret_cast<const rg_f32x4*>(p.b2 + 4 * lane);
@@ -570,16 +585,16 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
       gg = *reinterpret_cast<const rg_f32x4*>(p.ln1_g + 4 * lane);
       bb = *reinterpret_cast<const rg_f32x4*>(p.ln1_b + 4 * lane);
     }
-    cs4 = cs4 * (1.0f / p.h_scale);
     rg_f32x4 rpre[NRW];
-    prefetch_rows(p.h, p.ldh, rpre);
+    prefetch_rows(p.h, rpre);
     xstamp();      // 22: loads requested
     rg_lds_barrier();      // every wave is done with X and H
     xstamp();      // 23
     acc_to_slab(acc2);
     rg_lds_barrier();
     xstamp();      // 24: slab written
-    row_pass(cs4, b4, rpre, facts_o, p.out, p.ldo, p.amax_out, QKV, gg, bb, QKV ? p.a_scale_q : 1.f);
+    cs4 = cs4 * p.inv_h_scale;
+    row_pass(cs4, b4, rpre, facts_o, p.out, QKV ? LDH : p.ldo, p.amax_out, QKV, gg, bb, QKV ? p.a_scale_q : 1.f);      // (q|k|v follows only where out is the trunk itself)
     xstamp();      // 25: row pass done
     if constexpr (QKV) rg_lds_barrier();      // X is complete, the slab has been read: the patches go over it
   }
@@ -588,7 +603,9 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   // ================================ phase C: q | k | v of the next block (rowgemm_wa_kernel's loop) ================================
   if constexpr (QKV) {
     waited = true;
-    float* const ws = slab + wave * (16 * 36);
+    // (two patches per wave, alternating over the row groups: group mt + 1 is written while group mt's rows are still
+    // being read back -- with one patch every group was an LDS write -> read round trip in series)
+    float* const ws0 = slab + wave * (NPATCH * 16 * 36);
     const int prow = lane >> 3, pc4 = (lane & 7) * 4;
     read_a(std::integral_constant<int, 0>{}, rg_lds);
 #pragma unroll 1
@@ -611,10 +628,11 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
       // the chunk's epilogue, per wave, through its private 16 x 36-float patch (rowgemm_wa_kernel): q -> fp32 rows, k / v -> planes
       const int nw = c * 256 + wave * 32 + pc4;
       rg_f32x4 cw = *reinterpret_cast<const rg_f32x4*>(p.csq + nw);
-      cw = cw * (1.0f / p.a_scale_q);
+      cw = cw * p.inv_a_scale_q;
       const float sc = c < 4 ? p.k_scale : p.v_scale;
 #pragma unroll
       for (int mt = 0; mt < RT; ++mt) {
+        float* const ws = ws0 + (mt & (NPATCH - 1)) * (16 * 36);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -626,13 +644,13 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
           rg_f32x4 v = *reinterpret_cast<const rg_f32x4*>(ws + (ps * 8 + prow) * 36 + pc4) * cw;
           if (mrow >= p.M) continue;
           if (c < 2) {
-            *reinterpret_cast<rg_f32x4*>(p.q + mrow * p.ldq + nw) = v;
+            *(__attribute__((address_space(1))) rg_f32x4*)(p.q + mrow * LDQ + nw) = v;
           } else {
             const Split2 s0 = split2h_pair(v[0] * sc, v[1] * sc);
             const Split2 s1 = split2h_pair(v[2] * sc, v[3] * sc);
-            unsigned short* o2 = p.kv2 + mrow * p.ldkv + (nw - 512);
-            *reinterpret_cast<rg_u32x2*>(o2) = rg_u32x2{s0.h, s1.h};
-            *reinterpret_cast<rg_u32x2*>(o2 + p.kv2_plane) = rg_u32x2{s0.l, s1.l};
+            unsigned short* o2 = p.kv2 + mrow * LDKV + (nw - 512);
+            *(__attribute__((address_space(1))) rg_u32x2*)(o2) = rg_u32x2{s0.h, s1.h};
+            *(__attribute__((address_space(1))) rg_u32x2*)(o2 + p.kv2_plane) = rg_u32x2{s0.l, s1.l};
           }
         }
       }
@@ -643,7 +661,6 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   rg_wait_vmcnt<0>();
   landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
   landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
-  asm volatile("" ::"v"(warm));
   stamp();      // last: drained
 }
 

@@ -29,6 +29,8 @@ struct RowConvArgs {
   const float* colscale;
   const float* amax_in;          // per-utterance bound of A (slot = row_slot[row])
   const int* row_slot;
+  int slot_G, slot_S, slot_nb;   // the same slots by arithmetic, clamp((row - slot_G) / slot_S, 0, slot_nb - 1) (slot_S = 0: slot 0):
+                                 // rowconv_wd_kernel computes them instead of loading row_slot (one level of dependent loads less)
   const float* bias;
   float* out;
   long ldo;
@@ -46,9 +48,13 @@ struct RowConvArgs {
   long alg_rows;
   int ablate;      // tuning aid (JV_RG_ABLATE, tuning builds): 1 no weight DMA in the loop, 2 no LDS reads + MFMAs, 4 no waits / barriers,
                    // 8 no A staging in the loop, 16 no epilogue
+  unsigned long long* stamps;      // tuning aid (JV_RB_STAMPS, tuning builds; rowconv_wd_kernel): [workgroup][8] last-wave s_memtime per phase
 };
 
 __device__ __attribute__((aligned(64))) const float rc_zero_page[16] = {};
+// what an absent (null) row mask reads as: the loads stay unconditional -- behind `mask ? mask[row] : 1` each became a branch
+// with its own s_waitcnt vmcnt(0) at the join
+__device__ __attribute__((aligned(16))) const unsigned char rc_ones_page[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 
 template <int RT> constexpr int rc_a_plane() { return (16 * RT + 16) * 64; }
 template <int RT> constexpr int rc_lds_bytes() { return 3 * 32768 + 2 * 2 * rc_a_plane<RT>() + 16 * RT * 8; }
@@ -358,6 +364,14 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
   const int m0 = blockIdx.x * R;
   const int NCH = p.Cin >> 5;
   const int total = 3 * NCH;
+  int stamp_i = 0;
+  auto stamp = [&]() {      // (compiled out unless JV_TUNING)
+    if (JV_STAMP(p)) {
+      if (lane == 0 && stamp_i < 8) atomicMax(&p.stamps[(long)blockIdx.x * 8 + stamp_i], (unsigned long long)__builtin_amdgcn_s_memtime());
+      ++stamp_i;
+    }
+  };
+  stamp();      // 0: start
 
   // warm this XCD's L2 with the weight planes (see rowgemm_kernel.h)
   float warm = 0.f;
@@ -414,59 +428,83 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
   load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
   advance_w();
 
-  // ---- per-row facts of this tile, read once here (two dependent loads per row) and kept in LDS for the epilogue:
-  // x = bits of 1 / a_scale of the row's utterance, y = its slot | flags
+  // ---- per-row facts of this tile (kept in LDS for the epilogue: x = bits of 1 / a_scale of the row's utterance, y = its slot |
+  // flags) and the staging plan of this thread's window rows.  ONE level of loads: the utterance slot of a row is computed
+  // (row geometry: slot_G / slot_S), not loaded; masks, measured bounds and the first window rows themselves are all requested
+  // unconditionally on clamped indices, and a masked row is zeroed by selection when it is staged.  (As a chain row -> mask ->
+  // slot -> bound -> rows, each level behind its own s_waitcnt vmcnt(0) -- which, vmcnt being in order, also sat out the cold
+  // weight fragments requested first -- the setup took 10 k cycles of a 64 k-cycle launch in the phase stamps.)
   int2* const rowinfo = reinterpret_cast<int2*>(rc_lds + A_OFF + 2 * A_BUF);      // 8 R bytes, then the slab
   constexpr int RI_KEEP = 1 << 29, RI_TRACK = 1 << 30;
-  if (tid < R) {
-    const long m = (long)m0 + tid;
-    int y = 0;
-    float inv = 0.f;
-    if (m < p.M) {
-      const int sl = p.row_slot[m];
-      inv = 1.0f / h3_scale_dev(p.amax_in[sl]);
-      y = sl;
-      if (!p.rowmask_out || p.rowmask_out[m] != 0) y |= RI_KEEP;
-      if (p.amax_out && (!p.row_mask || p.row_mask[m] != 0)) y |= RI_TRACK;
-    }
-    rowinfo[tid] = int2{(int)__float_as_uint(inv), y};
-  }
-
-  // ---- A window staging: thread -> (window row, float4) pairs, fixed over the chunks
+  auto slot_of = [&](const long row) -> int {
+    if (p.slot_S <= 0) return 0;
+    const int q = (int)((row - p.slot_G) / p.slot_S);
+    return q < 0 ? 0 : (q >= p.slot_nb ? p.slot_nb - 1 : q);
+  };
   const float* asrc[NI];
-  int astep[NI], adst[NI];
-  float ascale[NI];
+  int adst[NI];
+  float ascale[NI];      // 0: the row reads as zero (outside the buffer, or masked)
+  bool ok[NI];
+  long arc[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int idx = tid + 512 * i;
     const int r = idx >> 3, c4 = idx & 7;
     const long ar = (long)m0 - 2 + r;
-    bool ok = r < WR && ar >= 0 && ar < p.a_rows;
-    if (ok && p.rowmask_in) ok = p.rowmask_in[ar] != 0;
-    asrc[i] = ok ? p.A + ar * p.lda + 4 * c4 : rc_zero_page;
-    astep[i] = ok ? 1 : 0;
-    ascale[i] = ok ? h3_scale_dev(p.amax_in[p.row_slot[ar]]) : 0.f;
+    ok[i] = r < WR && ar >= 0 && ar < p.a_rows;
+    arc[i] = ar < 0 ? 0 : (ar < p.a_rows ? ar : p.a_rows - 1);
+    asrc[i] = p.A + arc[i] * p.lda + 4 * c4;
     adst[i] = r < WR ? r * 64 + ((((c4 >> 1) ^ rg_key(r)) << 4) | ((c4 & 1) << 3)) : -1;
   }
   rg_f32x4 pa[NI];
   auto load_A = [&](int c) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)      // explicitly GLOBAL loads: a generic pointer (A or the zero page) would make them flat_load, which
-                                      // counts on lgkmcnt as well and returns out of order -- no counted wait is valid beside it
-      pa[i] = *(const __attribute__((address_space(1))) rg_f32x4*)(asrc[i] + c * 32 * astep[i]);
+    for (int i = 0; i < NI; ++i)      // explicitly GLOBAL loads (a generic pointer would make them flat_load: lgkmcnt as well, out of order)
+      pa[i] = *(const __attribute__((address_space(1))) rg_f32x4*)(asrc[i] + c * 32);
   };
   auto store_A = [&](int buf) {
     unsigned char* const base = rc_lds + A_OFF + buf * A_BUF;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       if (adst[i] >= 0) {
-        const Split2 s0 = split2h_pair(pa[i][0] * ascale[i], pa[i][1] * ascale[i]);
-        const Split2 s1 = split2h_pair(pa[i][2] * ascale[i], pa[i][3] * ascale[i]);
+        const bool use = ascale[i] != 0.f;      // (a row that reads as zero may hold anything, NaN included: selected, never multiplied)
+        const Split2 s0 = split2h_pair(use ? pa[i][0] * ascale[i] : 0.f, use ? pa[i][1] * ascale[i] : 0.f);
+        const Split2 s1 = split2h_pair(use ? pa[i][2] * ascale[i] : 0.f, use ? pa[i][3] * ascale[i] : 0.f);
         *reinterpret_cast<rg_u32x2*>(base + adst[i]) = rg_u32x2{s0.h, s1.h};
         *reinterpret_cast<rg_u32x2*>(base + A_PLANE + adst[i]) = rg_u32x2{s0.l, s1.l};
       }
     }
   };
+  load_A(0);      // the first window's rows travel with the facts below
+  {
+    typedef const __attribute__((address_space(1))) unsigned char* gbytes;
+    const long mt = (long)m0 + (tid < R ? tid : 0);
+    const long mc = mt < p.M ? mt : (long)p.M - 1;
+    const int sl_o = slot_of(mc);
+    const int keep_o = ((gbytes)(p.rowmask_out ? p.rowmask_out : rc_ones_page))[p.rowmask_out ? mc : 0];
+    const int trk_o = ((gbytes)(p.row_mask ? p.row_mask : rc_ones_page))[p.row_mask ? mc : 0];
+    const float am_o = p.amax_in[sl_o];
+    int mk_i[NI];
+    float am_i[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      mk_i[i] = ((gbytes)(p.rowmask_in ? p.rowmask_in : rc_ones_page))[p.rowmask_in ? arc[i] : 0];
+      am_i[i] = p.amax_in[slot_of(arc[i])];
+    }
+    if (tid < R) {
+      int y = 0;
+      float inv = 0.f;
+      if (mt < p.M) {
+        inv = 1.0f / h3_scale_dev(am_o);
+        y = sl_o;
+        if (keep_o != 0) y |= RI_KEEP;
+        if (p.amax_out && trk_o != 0) y |= RI_TRACK;
+      }
+      rowinfo[tid] = int2{(int)__float_as_uint(inv), y};
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) ascale[i] = (ok[i] && mk_i[i] != 0) ? h3_scale_dev(am_i[i]) : 0.f;
+  }
 
   rg_f32x4 acc[RT][2];
 #pragma unroll
@@ -483,13 +521,14 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
     gg = *reinterpret_cast<const rg_f32x4*>(p.ln_g + 4 * lane);
     bb = *reinterpret_cast<const rg_f32x4*>(p.ln_b + 4 * lane);
   }
-  load_A(0);
+  stamp();      // 1: row facts and staging addresses set up
   store_A(0);
   if (NCH > 1) load_A(1);
   // both steps' fragments (and everything older) have landed once only the A loads of chunk 1 are outstanding
   if (NCH > 1) rg_wait_vmcnt<NI>(); else rg_wait_vmcnt<0>();
   landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
   landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
+  stamp();      // 2: first window staged, first fragments landed
 
   // One step = (chunk c, tap j): block 0 (column block 0 x all row groups, A fragments at row offset j of the chunk's window),
   // reload bq[par][0] for step s + 2, counted wait, block 1, reload bq[par][1].  This wave's vector-memory operations in
@@ -550,6 +589,7 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
   // ---- epilogue: the whole tile through ONE slab laid over the (now idle) weight ring -- a single chunk has nothing left to
   // prefetch -- then 2 RT rows per wave, RT at a time so that their loads, reductions and transcendentals overlap.  (In 32-row
   // passes through a slab of their own, two barriers each, the tail took 13 - 19 us of a 50 us launch.)
+  stamp();      // 3: main loop done
   if (JV_ABLATE(p, 16)) return;
   const bool mish = p.act == ACT_MISH;      // (uniform) the one activation the estimator uses here
   float* const slab = reinterpret_cast<float*>(rc_lds + SLAB_OFF);      // its own region: nothing to wait for before writing it
@@ -639,9 +679,12 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
     RowIn in0, in1;
     request(std::integral_constant<int, 0>{}, in0);      // (rowinfo was written by this workgroup's threads ahead of the main loop's barriers)
     rg_lds_barrier();
+    stamp();      // 4: slab written, barrier passed
     request(std::integral_constant<int, 1>{}, in1);
     rows(std::integral_constant<int, 0>{}, in0);
+    stamp();      // 5: first row group done
     rows(std::integral_constant<int, 1>{}, in1);
+    stamp();      // 6: second row group done
   }
   rg_wait_vmcnt<0>();      // the wrapped-around W loads: bq stays reserved until they have landed (rowgemm_wd_kernel)
   landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);

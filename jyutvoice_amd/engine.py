@@ -336,6 +336,21 @@ def op_rowconv(A, W, bias=None, ln=None, act="none", rowmask=None, rowvec=None, 
     return out
 
 
+def op_hiftconv(A, W, bias, alpha, ntaps, dil, rowmask=None, res1=None, res2=None, out_scale=1.0, prev=None, amax_out=None):
+    """hiftconv_kernel.h: the vocoder's ResBlock convolution on a [rows, C] row buffer (C = 64 / 128 / 256); W [C, ntaps * C]
+    tap-major; prev: accumulate onto this tensor"""
+    lib = _lib.load()
+    rows, C = A.shape
+    out = prev.clone() if prev is not None else torch.empty(rows, C, device=A.device)
+    masked = A if rowmask is None else A * rowmask[:, None].to(A.dtype)
+    amax_in = torch.nan_to_num(masked).abs().max().reshape(1)
+    extra = float((1.0 / (alpha + 1e-9)).max())
+    check(lib.jv_op_hiftconv(_ptr(A), rows, C, int(ntaps), int(dil), _ptr(W), _ptr(bias), _ptr(alpha), _ptr(rowmask), _ptr(res1),
+                             _ptr(res2), float(out_scale), 1 if prev is not None else 0, _ptr(amax_in), extra, _ptr(amax_out),
+                             _ptr(out), _stream(A.device)))
+    return out
+
+
 def op_layernorm(x, g, b, eps=1e-5):
     lib = _lib.load()
     out = torch.empty_like(x)

@@ -597,6 +597,45 @@ def test_attention_rows(dev, monkeypatch, B, L, lens, qt):
         assert torch.equal(op_attention_planes(qkv.to(dev), lens_t.to(dev), B, G, S, L, bounds), first), i
 
 
+@pytest.mark.parametrize("k,dil,C,rows", [(11, 5, 64, 1500), (7, 3, 128, 700), (3, 1, 256, 333), (11, 5, 256, 250), (7, 1, 64, 321),
+                                          (3, 5, 128, 161), (11, 1, 128, 40)])
+def test_hiftconv(dev, k, dil, C, rows):
+    """hiftconv_kernel.h (the vocoder's ResBlock convolutions, row-owning: the whole Snake'd window in LDS, weights in fragment
+    order) against fp64 and torch's own conv1d: every kernel size / dilation / channel count of generator.py:90-97, several
+    workgroups with a ragged last one and windows that reach past both ends of the buffer, masked rows holding NaN (selected,
+    never multiplied), both residuals + scaling + accumulation, and the measured-bound tracking of what is stored"""
+    from jyutvoice_amd.engine import op_hiftconv
+    g = torch.Generator().manual_seed(k * 1000 + dil * 100 + C)
+    A = torch.randn(rows, C, generator=g) * 2
+    w = torch.randn(C, C, k, generator=g) / math.sqrt(k * C)
+    b = torch.randn(C, generator=g) * 0.1
+    alpha = 1 + 0.1 * torch.randn(C, generator=g).abs()
+    res1, res2, prev = (torch.randn(rows, C, generator=g) for _ in range(3))
+    mask = (torch.rand(rows, generator=g) > 0.1).to(torch.uint8)
+    Abad = A.clone()
+    Abad[mask == 0] = float("nan")                      # what a masked row holds must not matter
+    pad = dil * (k - 1) // 2
+    Ad = (A * mask[:, None]).double()
+    sn = Ad + (1.0 / (alpha.double() + 1e-9)) * torch.sin(Ad * alpha.double()) ** 2
+    sn = sn * mask[:, None].double()                    # masked rows read as zero AFTER the activation too (Snake(0) = 0)
+    conv = F.conv1d(sn.T[None], w.double(), b.double(), dilation=dil, padding=pad)[0].T
+    # plain
+    out = op_hiftconv(A.to(dev), pack_conv(w).to(dev), b.to(dev), alpha.to(dev), k, dil, rowmask=mask.to(dev))
+    assert float((out.double().cpu() - conv).abs().max()) < 2e-5
+    # NaN in masked rows, residuals, scale, accumulation, tracking
+    amax = torch.zeros(1, device=dev)
+    out = op_hiftconv(Abad.to(dev), pack_conv(w).to(dev), b.to(dev), alpha.to(dev), k, dil, rowmask=mask.to(dev), res1=res1.to(dev),
+                      res2=res2.to(dev), out_scale=1.0 / 3.0, prev=prev.to(dev), amax_out=amax)
+    want = ((conv + res1.double()) + res2.double()) / 3.0 + prev.double()
+    assert float((out.double().cpu() - want).abs().max()) < 2e-5
+    tracked = out.cpu()[mask.bool()].abs().max()
+    assert float(amax.cpu()) == float(tracked)          # exactly the largest stored magnitude over unmasked rows
+    # in place on a residual (c2 of a ResBlock writes the buffer it adds)
+    buf = res1.clone().to(dev)
+    inpl = op_hiftconv(A.to(dev), pack_conv(w).to(dev), b.to(dev), alpha.to(dev), k, dil, rowmask=mask.to(dev), res1=buf)
+    assert float((inpl.double().cpu() - (conv + res1.double())).abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize("rt", ["2", "3", "5"])
 @pytest.mark.parametrize("cin", [256, 512, 64])
 def test_rowconv(dev, monkeypatch, rt, cin):
