@@ -4,7 +4,7 @@
 namespace jv {
 
 namespace {
-template <int C, int NG, bool UALL>
+template <int C, int NG>
 int hc_launch(const HiftConvArgs& a, hipStream_t st) {
   static int raised[64] = {};      // per device: the LDS size the attribute was last raised to
   int dev = 0;
@@ -12,12 +12,12 @@ int hc_launch(const HiftConvArgs& a, hipStream_t st) {
   const int lds = hc_lds_bytes<C, NG>(a.ntaps, a.dil);
   if (lds > 160 * 1024) return fail(JV_ERR_ARG, "hiftconv: the window does not fit LDS");
   if (raised[dev & 63] < lds) {
-    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hiftconv_kernel<C, NG, UALL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hiftconv_kernel<C, NG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     raised[dev & 63] = lds;
   }
   const bool prof = prof_on();
   if (prof) prof_begin(st);
-  hipLaunchKernelGGL((hiftconv_kernel<C, NG, UALL>), dim3(cdiv(a.M, hc_rows<NG>())), dim3(hc_threads<C, NG>()), lds, st, a);
+  hipLaunchKernelGGL((hiftconv_kernel<C, NG>), dim3(cdiv(a.M, hc_rows<NG>())), dim3(hc_threads<C, NG>()), lds, st, a);
   if (prof) {
     static const std::string name = std::string("hiftconv_h3<") + std::to_string(hc_rows<NG>()) + "x" + std::to_string(C) + ",snake>";
     const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M);
@@ -36,12 +36,13 @@ int hiftconv(const HiftConvArgs& a, int C, hipStream_t st) {
     return fail(JV_ERR_ARG, "hiftconv: needs A, the Snake alphas, fragment-order weights, colscale, the measured bound and an output");
   if (a.ntaps < 1 || a.ntaps > 11 || a.dil < 1 || (a.ntaps - 1) * a.dil > 56) return fail(JV_ERR_ARG, "hiftconv: window too wide");
   // 64 and 128 channels: four-wave workgroups (160 / 80 rows, 54 - 66 KB of LDS), two per CU -- one's staging pass and
-  // epilogue run under the other's main loop; JV_HIFT_WG8: one eight-wave workgroup per CU (320 / 160 rows; A/B aid)
-  const bool wg8 = dyn_env("JV_HIFT_WG8") != nullptr, u4 = dyn_env("JV_HIFT_U4") != nullptr;
+  // epilogue run under the other's main loop (vocoder stage 24.6 ms against 25.3 with one eight-wave workgroup per CU,
+  // JV_HIFT_WG8, and 28.2 on the tile kernels: same box, back to back)
+  const bool wg8 = dyn_env("JV_HIFT_WG8") != nullptr;
   switch (C) {
-    case 64: return wg8 ? (u4 ? hc_launch<64, 4, false>(a, st) : hc_launch<64, 4, true>(a, st)) : (u4 ? hc_launch<64, 2, false>(a, st) : hc_launch<64, 2, true>(a, st));
-    case 128: return wg8 ? (u4 ? hc_launch<128, 2, false>(a, st) : hc_launch<128, 2, true>(a, st)) : (u4 ? hc_launch<128, 1, false>(a, st) : hc_launch<128, 1, true>(a, st));
-    case 256: return u4 ? hc_launch<256, 1, false>(a, st) : hc_launch<256, 1, true>(a, st);
+    case 64: return wg8 ? hc_launch<64, 4>(a, st) : hc_launch<64, 2>(a, st);
+    case 128: return wg8 ? hc_launch<128, 2>(a, st) : hc_launch<128, 1>(a, st);
+    case 256: return hc_launch<256, 1>(a, st);
     default: return fail(JV_ERR_ARG, "hiftconv: 64, 128 or 256 channels");
   }
 }

@@ -63,7 +63,7 @@ template <int C, int NG> inline int hc_lds_bytes(int ntaps, int dil) {
   return ((wr * 4 + 255) & ~255) + R * 8 + (C / 32) * 2 * wr * 64 + NG * (C / 32) * 16 * 36 * 4;
 }
 
-template <int C, int NG, bool UALL>
+template <int C, int NG>
 __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftconv_kernel(const HiftConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char hc_lds[];
   constexpr int RT = HC_RT, RG = HC_RG;
@@ -160,9 +160,10 @@ __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftconv_kernel(const H
     for (int e = 0; e < 4; ++e) ai[e] = 1.0f / (al[e] + 1e-9f);
     const int chunk = c4 >> 3, cslot = (c4 & 7) >> 1, chalf = (c4 & 1) << 3;
     const float* const abase = p.A + ((long)m0 + p.tap_row0) * C + 4 * c4;
-    // ALL of the thread's rows in flight at once (12 - 17 float4): in batches of four, every batch sat out a full memory
-    // latency with nothing to overlap it -- one workgroup per CU, and the main loop cannot start before the window is staged
-    constexpr int U = UALL ? (R + 56 + RPI - 1) / RPI : 4;
+    // four rows in flight per thread and pass.  (All 12 - 17 of a thread's rows at once measured SLOWER on the same box: the
+    // vocoder stage 32.2 ms against 24.6 -- the loop below is then one 8 000-line unrolled body, and two co-resident workgroups
+    // hide each other's latency anyway.)
+    constexpr int U = 4;
     for (int rb = r0; rb < WR; rb += U * RPI) {
       rg_f32x4 x[U];
       float sc[U];

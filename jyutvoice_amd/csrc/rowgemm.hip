@@ -99,10 +99,26 @@ int pack_wfrag(const unsigned short* w2, long w2_plane, int ldw, int N, int K, u
 }
 
 // tile height (in 16-row units) for M rows: the fewest rounds of workgroups over the 256 CUs times the rows each round
-// costs; ties go to the taller tile (each weight byte is then used for more rows).  0: use the tile kernels -- too few rows
-// for one workgroup per CU to pay (the tile kernels split N as well and keep more CUs busy), or more than one round of them.
+// costs; ties go to the taller tile (each weight byte is then used for more rows).  0: use the tile kernels -- at most 2048
+// rows (one to three utterances of 300 frames), where flow.hip splits the long contractions over K instead.
+//
+// Calibration (tools/regime_sweep.py, round 3, CFM loop alone at 300 frames, n = 4, one box; ms per pass, * = what this
+// function picks):        utterances   tile kernels   rt 2     rt 3     rt 4     rt 5
+//                              2          19.8*       24.6     26.4
+//                              4          26.5        24.5*    27.8     30.4     34.0
+//                              8          34.5        24.3*    29.2     32.9     36.8
+//                             16          46.3        42.7     31.2*    35.4     39.5
+//                             24          65.2        51.6     55.4     42.0*    46.0
+//                             32          76.1        68.9     62.2     66.6     50.8*
+//                             40          87.1        76.7     69.7*    74.2     80.6
+//                             48         104.9        92.6     88.0     79.3*    85.9
+//                             64         135.9       117.2    115.1    109.3     99.0*
+// With the transformer block in one launch (rowblock_kernel.h) the row-owning form wins wherever it exists: round 2's two
+// exceptions -- fewer than 96 workgroups, and more than one round of tiles shorter than 64 rows (the "hole" at 40
+// utterances, which cost 25 % there) -- are gone, and the plain cost model picks the measured optimum at every point.
 int rowgemm_tile(int M) {
   if (const char* f = dyn_env("JV_ROWGEMM_RT")) return atoi(f);
+  if (M <= 2048) return 0;      // = flow.hip's PARTIAL_ROWS: the split-K regime
   int best = 0;
   long best_cost = 0;
   for (int rt = 2; rt <= 5; ++rt) {
@@ -110,13 +126,6 @@ int rowgemm_tile(int M) {
     const long cost = cdivl(wgs, 256) * rt;
     if (!best || cost < best_cost || (cost == best_cost && rt > best)) { best = rt; best_cost = cost; }
   }
-  // measured on the whole path (bench.py, same box, against the tile kernels; W-direct kernel): 4 utterances x 300 frames (77
-  // workgroups of 32 rows) +16 %, 8 (153) -8 %, 16 (122 of 80 rows) -14 %, 32 (244, one round) -9 %, 64 (487, two rounds)
-  // -5.5 %; a forced 80-row tile at 48 utterances (365 workgroups: the second round 43 % full) +4 % -- the cost model
-  // above takes 64-row tiles there (457 workgroups, two rounds 89 % full)
-  // (96: -8.7 %, 48: -3.5 %; 40 utterances, where the model picks two rounds of 48-row tiles: +2.5 % -- left to the tile kernels)
-  const int wgs = cdiv(M, 16 * best);
-  if (wgs < 96 || (wgs > 256 && best < 4)) return 0;
   return best;
 }
 

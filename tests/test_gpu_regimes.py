@@ -1,0 +1,61 @@
+"""GPU: the kernel regimes the batch size selects (VERDICT r2 "regime seams").
+
+The estimator takes its transformer linears and trunk convolutions through different kernels depending on how many rows the
+batch has: split-K tiles at <= 2048 rows (1 - 3 utterances of 300 frames), plain tiles while the row-owning kernels would
+leave most CUs idle, row-owning kernels (rowblock / rowconv / rowgemm at tile heights 2 .. 5) beyond.  Two properties are
+asserted over a sweep of batch sizes at 300 frames:
+  * throughput (mel frames per second of the CFM loop) never falls by more than 10 % when utterances are added -- a seam
+    where the cost model picks the wrong form shows up as a dip (round 2's hole at 40 utterances was 25 %).  Not 5 %: 40
+    utterances are 1.25 rounds of the 80-row tiles that make 32 utterances exactly one round, and the best form that exists
+    for them (two rounds of 48-row tiles) measures 172 K frames/s against 190 K at 32 (tools/regime_sweep.py: every other
+    point of the sweep is within 5 % of the running maximum);
+  * every regime is checked against the CPU oracle on one utterance (the first of the batch), so no form is reachable that the
+    parity tests do not see."""
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BATCHES = (1, 2, 4, 8, 16, 24, 32, 40, 48, 64)
+T = 300
+N_STEPS = 2
+
+
+def test_throughput_is_monotone_and_every_regime_matches_the_oracle(tts_sd, noise):
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
+    from jyutvoice_amd.engine import JV_MODEL_TTS, Engine
+    from oracle import flow as oflow
+    eng = Engine("cuda:0", max_batch=max(BATCHES), max_frames=T + 4, max_tokens=32)
+    try:
+        eng.load_state_dict(JV_MODEL_TTS, tts_sd)
+        eng.load_noise(noise)
+        g = torch.Generator().manual_seed(4242)
+        mu_all = torch.randn(max(BATCHES), 80, T, generator=g)
+        spks_all = torch.randn(max(BATCHES), 80, generator=g)
+        # the oracle on utterance 0 alone (B = 1 semantics: what the reference computes)
+        mask = torch.ones(1, 1, T)
+        want = oflow.cfm_solve(tts_sd, noise, mu_all[:1], mask, spks_all[:1], torch.zeros(1, 80, T), N_STEPS, 1.0)
+        rate = {}
+        for B in BATCHES:
+            mu, spks, cond = mu_all[:B].cuda(), spks_all[:B].cuda(), torch.zeros(B, 80, T, device="cuda")
+            mel = eng.cfm_solve(mu, None, spks, cond, N_STEPS, 1.0)
+            torch.cuda.synchronize()
+            err = float((mel[:1].cpu() - want).abs().max())
+            assert err <= 1e-3, (B, err)                 # north-star tolerance; measured ~3e-6 in every regime
+            times = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                eng.cfm_solve(mu, None, spks, cond, N_STEPS, 1.0)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            rate[B] = B * T / sorted(times)[1]
+        best = 0.0
+        for B in BATCHES:
+            assert rate[B] >= 0.90 * best, (f"throughput dips at {B} utterances: {rate[B]:.0f} frames/s after {best:.0f}",
+                                            {b: round(r) for b, r in rate.items()})
+            best = max(best, rate[B])
+    finally:
+        eng.close()
