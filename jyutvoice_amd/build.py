@@ -22,6 +22,9 @@ OBJ = os.path.join(CSRC, "build", TAG) if TAG else os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, f"libjyutvoice_hip.{TAG}.so" if TAG else "libjyutvoice_hip.so")
 # -fno-slp-vectorize: packed f32 VALU (v_pk_add/mul/fma_f32) issues slower than the scalar pair beside MFMAs on gfx950
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result", "-fno-slp-vectorize"]
+# per-file additions.  attention_s.hip owns the wave's 256 AGPRs by name inside its inline asm (O tiles and the high Q planes):
+# the compiler must not park spilled VGPRs there (tools/check_rowgemm_isa.py checks the ISA for any AGPR use of its own)
+FILE_FLAGS = {"attention_s.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
 FLAGS += os.environ.get("JV_EXTRA_FLAGS", "").split()
 if os.environ.get("JV_TUNING"):      # ablation switches + in-kernel stamps (tools/gemm_bench.py); use with --force
     FLAGS.append("-DJV_TUNING")
@@ -63,7 +66,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def cc(job):
         s, o = job
-        r = subprocess.run([hipcc, *FLAGS, "-c", s, "-o", o], capture_output=True, text=True)
+        r = subprocess.run([hipcc, *FLAGS, *FILE_FLAGS.get(os.path.basename(s), []), "-c", s, "-o", o], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{r.stdout}\n{r.stderr}")
         return s

@@ -109,6 +109,7 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   c.no_attn_planes = getenv("JV_NO_ATTN_PLANES") != nullptr;
   c.no_hiftconv = getenv("JV_NO_HIFTCONV") != nullptr;
   c.attn_rows = getenv("JV_ATTN_ROWS") != nullptr;
+  c.attn_single = getenv("JV_NO_ATTN_SINGLE") == nullptr;
   c.max_frames = max_frames;
   c.max_tokens = max_tokens;
   jv::build_registry(c);
@@ -565,6 +566,7 @@ int jv_op_attention_planes(const float* qkv, int64_t rows, const int32_t* lens, 
   at.kv2 = kv; at.kv2_plane = plane; at.kv_ld = 1024;
   if (out2) { at.out2 = out2; at.out2_plane = (long)rows * 512; at.out2_scale = out2_scale; }
   if (chunk == 0 && jv::dyn_env("JV_OP_ATTN_ROWS")) return jv::attention64_rows(at, st);      // the row-owning form (attention_r.hip)
+  if (chunk == 0 && jv::dyn_env("JV_OP_ATTN_SINGLE")) return jv::attention64_single(at, st);  // one wave per SIMD (attention_s.hip)
   return jv::attention64_planes(at, st);
 }
 

@@ -406,7 +406,8 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
         JV_TRY(rowgemm(a, RG_QKV, st));
       }
       at.ld = 512; at.kv2 = kv2; at.kv2_plane = R * 1024; at.kv_ld = 1024;
-      if (at.chunk == 0 && c.attn_rows) JV_TRY(attention64_rows(at, st));      // one workgroup per head, 80 queries per wave (opt-in)
+      if (c.attn_single && attention64_single_fits(at)) JV_TRY(attention64_single(at, st));      // one wave per SIMD, 160 queries per wave (whole-utterance attention; JV_NO_ATTN_SINGLE: attn64_pl)
+      else if (at.chunk == 0 && c.attn_rows) JV_TRY(attention64_rows(at, st));      // one workgroup per head, 80 queries per wave (opt-in)
       else JV_TRY(attention64_planes(at, st));
     } else {
       a.out = w.qkv; a.ldo = 1536;

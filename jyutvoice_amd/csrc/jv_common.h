@@ -200,6 +200,8 @@ struct AttnArgs {
 int attention64(const AttnArgs& a, hipStream_t st);
 int attention64_planes(const AttnArgs& a, hipStream_t st);
 int attention64_rows(const AttnArgs& a, hipStream_t st);      // attention_r.hip: attention64_planes' contract, chunk == 0 only
+int attention64_single(const AttnArgs& a, hipStream_t st);    // attention_s.hip: the same, one wave per SIMD, software-pipelined
+bool attention64_single_fits(const AttnArgs& a);              // ... and whether its workgroups fill their rounds of the chip
 
 // ---- row-wise / elementwise kernels (rowops.hip) -------------------------------------------------
 // out = LayerNorm_C(x (+ add)) * g + b, optional ReLU, rows with rowmask_out == 0 written as zero

@@ -134,6 +134,7 @@ struct Context {
   bool no_ffn_fuse = false;      // JV_NO_FFN_FUSE=1: ff.net.0 and ff.net.2 as two launches (the path rowffn_kernel is checked against)
   bool no_block_fuse = false;    // JV_NO_BLOCK_FUSE=1: to_out / feed-forward / next q|k|v as three launches (the path rowblock_kernel is checked against)
   bool rg_ff1 = true;            // ff.net.0 on the row-owning GEMM too; JV_TILE_FF1=1: on the tile kernel (the round-2 first build, for A/B runs)
+  bool attn_single = true;       // attention_s.hip for whole-utterance attention (one wave per SIMD, software-pipelined); JV_NO_ATTN_SINGLE=1: attention_pl.hip
   bool attn_rows = false;        // JV_ATTN_ROWS=1: the estimator's attention on attention_r.hip (one workgroup per head, 80 queries per wave; measured
                                  // 66.6 us against attention_pl.hip's 60.0 at 32 x 300 frames: kept as a tested alternative)
   bool no_hiftconv = false;      // JV_NO_HIFTCONV=1: the vocoder's ResBlock convolutions on the tile kernels (A/B aid; the path hiftconv_kernel is checked against)

@@ -562,13 +562,14 @@ def test_attention_planes(dev, B, L, lens):
 @pytest.mark.parametrize("B,L,lens", [(2, 300, [300, 217]), (3, 70, [70, 1, 33]), (1, 512, [512]), (2, 40, [40, 40]),
                                       (2, 129, [129, 64]), (2, 330, [330, 321]), (1, 1100, [1093])])
 @pytest.mark.parametrize("qt", [None, "2", "3"])
-def test_attention_rows(dev, monkeypatch, B, L, lens, qt):
+@pytest.mark.parametrize("form", ["JV_OP_ATTN_ROWS", "JV_OP_ATTN_SINGLE"])
+def test_attention_rows(dev, monkeypatch, B, L, lens, qt, form):
     """attention_r.hip (one workgroup per head and 64 QT queries, a wave's K / V^T fragments used for QT 16-query tiles,
     v_mfma_f32_16x16x32_f16, per-lane row sums) against fp64: its own choice of QT and forced smaller ones (several
     workgroups per head, idle waves), ragged key masks incl. a last key tile that straddles the mask, fp32 and fp16-plane
     output; identical bits over repeated launches beside a streaming writer (the DMA ring)"""
     from jyutvoice_amd.engine import op_attention_planes
-    monkeypatch.setenv("JV_OP_ATTN_ROWS", "1")
+    monkeypatch.setenv(form, "1")      # attention_r.hip (80 queries per wave) / attention_s.hip (160, one wave per SIMD)
     if qt:
         monkeypatch.setenv("JV_ATTN_QT", qt)
     g = torch.Generator().manual_seed(B * 1000 + L + 17)

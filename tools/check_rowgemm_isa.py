@@ -8,6 +8,10 @@ nothing except (a) the asm loads, (b) v_mfma instructions reading them as an ope
 first load (the straight-line prologue, where nothing is in flight in it yet).  A register-allocator copy or spill of one of them while a load is in flight would read stale data without
 any tool noticing.  This script compiles rowgemm.hip and rowblock.hip to assembly and asserts exactly that for every instantiation.
 
+Second check, attention_s.hip (attn64_s_kernel): that kernel keeps its O accumulators and high Q planes in AGPRs it names
+itself inside inline asm (a32 and up), without telling the compiler.  Sound only if the compiler-generated code of the kernel
+touches no AGPR from a32 up and spills nothing (a scratch reload would not be a hazard, but the kernel is written to fit): asserted here.
+
 usage: python tools/check_rowgemm_isa.py   (exit code 0 = clean)"""
 import os
 import re
@@ -18,7 +22,8 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRCS = [os.path.join(ROOT, "jyutvoice_amd", "csrc", f) for f in ("rowgemm.hip", "rowblock.hip")]
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-fno-slp-vectorize", "-x", "hip", "--cuda-device-only", "-S"]
+ATTN_S = os.path.join(ROOT, "jyutvoice_amd", "csrc", "attention_s.hip")
+FLAGS0 = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-fno-slp-vectorize", "-x", "hip", "--cuda-device-only", "-S"]
 
 REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
 
@@ -88,11 +93,45 @@ def check_kernel(name, body):
     return len(loads), bad
 
 
+AGPR = re.compile(r"(?<![\w.])a\[?(\d+)(?::(\d+))?")
+AGPR_OWN = 32      # attention_s.hip leaves a[0:31] to the compiler
+
+
+def check_agpr_owner(name, body):
+    """no AGPR operand from a32 up and no scratch access outside inline asm"""
+    bad = []
+    in_asm = False
+    n_asm = 0
+    for i, ln in enumerate(body.split("\n")):
+        t = ln.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            n_asm += 1
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        t = t.split(";")[0].strip()
+        if in_asm or not t or t.endswith(":") or t.startswith("."):
+            continue
+        parts = t.split(None, 1)
+        if parts[0].startswith("scratch_"):
+            bad.append((i, ln))
+        elif len(parts) > 1:
+            for m in AGPR.finditer(parts[1]):
+                if max(int(m.group(1)), int(m.group(2) or 0)) >= AGPR_OWN:
+                    bad.append((i, ln))
+    return n_asm, bad
+
+
 def main():
     s = ""
+    sys.path.insert(0, ROOT)
+    from jyutvoice_amd.build import FILE_FLAGS      # the per-file flags the library is built with
     with tempfile.TemporaryDirectory() as d:
-        for src in SRCS:
-            out = os.path.join(d, os.path.basename(src) + ".s")
+        for src, extra in [(f, []) for f in SRCS + [ATTN_S]] + [(ATTN_S, ["-DJV_TUNING"])]:      # (the tuning build's variants too)
+            out = os.path.join(d, os.path.basename(src) + (".tune" if extra else "") + ".s")
+            FLAGS = FLAGS0 + FILE_FLAGS.get(os.path.basename(src), []) + extra
             r = subprocess.run([CLANG] + FLAGS + ["-o", out, src], capture_output=True, text=True)
             if r.returncode != 0:
                 print(r.stderr[-3000:])
@@ -115,6 +154,16 @@ def main():
             n_bad += 1
         for i, ln in bad:
             print("FAIL", name, "line", i, ":", ln.strip())
+            n_bad += 1
+    for m in re.finditer(r"^(_ZN2jv\w*attn64_s_kernel\w+):\s*;.*?\n(.*?)\.end_amdhsa_kernel", s, re.S | re.M):
+        name, body = m.group(1), m.group(2).split("s_endpgm")[0]
+        n_asm, bad = check_agpr_owner(name, body)
+        n_k += 1
+        if n_asm == 0:
+            print("FAIL", name, ": no inline asm found")
+            n_bad += 1
+        for i, ln in bad:
+            print("FAIL", name, "line", i, ": compiler-generated AGPR / scratch use:", ln.strip())
             n_bad += 1
     print(f"checked {n_k} kernels, {n_bad} violations")
     return 1 if (n_bad or n_k == 0) else 0

@@ -82,7 +82,7 @@ for L in ((int(os.environ["JV_ATTN_L"]),) if os.environ.get("JV_ATTN_L") else (3
     B = 64 if L == 300 else 16
     S = L + 4
     qkv = torch.randn(4 + B * S + 8, 1536, generator=g).to(dev)
-    lens = torch.full((B,), L, dtype=torch.int32, device=dev)
+    lens = torch.full((B,), int(os.environ.get("JV_ATTN_LEN", L)), dtype=torch.int32, device=dev)      # JV_ATTN_LEN: valid keys (fewer key tiles, same queries)
     if os.environ.get("JV_OP_ATTN_PL"):      # K / V as planes by LDS-DMA (attention_pl.hip)
         bounds = tuple(8.0 * float(qkv[:, o:o + 512].abs().max()) for o in (0, 512, 1024))
         t = timeit(lambda: op_attention_planes(qkv, lens, B, 4, S, L, bounds))
