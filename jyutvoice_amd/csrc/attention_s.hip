@@ -552,6 +552,33 @@ void launch_s(const AttnArgs& a, hipStream_t st) {
 }  // namespace
 
 static int single_qt(const AttnArgs& a) {
+  // queries per workgroup = 64 QT: the QT in {2 .. 5} with the fewest padded queries, the taller tile on a tie
+  int qt = 5;
+  long best = 1L << 40;
+  for (int c = 5; c >= 2; --c) {
+    const long padded = (long)cdiv(a.L, 64 * c) * 64 * c;
+    if (padded < best) { qt = c; best = padded; }
+  }
+  return qt;
+}
+
+// Is this the form to use?  One wave per SIMD means 512 workgroups are one round of the chip and 513 are two: the form pays
+// when its workgroups fill their rounds (32 or 64 utterances of <= 320 frames x 8 heads: 512 / 1024); at 40 utterances
+// (640 workgroups: 1.25 rounds run as 2) attn64_pl's small workgroups lose less.  tests/test_gpu_regimes.py holds the seam.
+bool attention64_single_fits(const AttnArgs& a) {
+  if (a.B <= 0 || a.L <= 0 || a.chunk != 0) return false;
+  const long wgs = (long)cdiv(a.L, AS_NW * 32 * single_qt(a)) * a.H * a.B;
+  const long slots = (long)cdiv(wgs, 512) * 512;
+  return wgs * 100 >= slots * 85;
+}
+
+// same contract as attention64_planes() (attention_pl.hip); no chunk-causal mask
+int attention64_single(const AttnArgs& a, hipStream_t st) {
+  if (a.B <= 0 || a.L <= 0) return JV_OK;
+  if (!a.kv2 || (a.kv_ld & 7) || !(a.q_scale > 0.f && a.k_scale > 0.f && a.v_scale > 0.f) || (a.ld & 3) || (a.ldo & 7) || a.chunk > 0)
+    return fail(JV_ERR_ARG, "attention64_single: needs K/V planes, the three scales, aligned strides, no chunk mask");
+  const bool prof = prof_on();
+  if (prof) prof_begin(st);
   int qt = single_qt(a);
   if (const char* f = dyn_env("JV_ATTN_QT")) qt = atoi(f);
   switch (qt) {
