@@ -26,6 +26,12 @@ def short(name):
     m = re.search(r"rowconv_(?:wd_)?kernel<(\d+)>", name)
     if m:
         return f"rowconv_h3<{16 * int(m.group(1))}x256,k3>"
+    m = re.search(r"attn64_s_kernel<(\d), \d+(?:, \d+)?>", name)
+    if m:
+        return f"attn64_s<{64 * int(m.group(1))} q>"
+    m = re.search(r"hiftconv_kernel<(\d+), (\d+)>", name)
+    if m:
+        return f"hiftconv_h3<{80 * int(m.group(2))}x{m.group(1)},snake>"
     m = re.search(r"attn64_pl_kernel<(\d)(?:, \d)?>", name)
     if m:
         return f"attn64_pl<{m.group(1)} waves>"
