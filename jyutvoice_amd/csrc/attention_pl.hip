@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (NST == 2 ? 4 : 3)) void att
 #pragma unroll
     for (int e = 1; e < 16; ++e) mt = fmaxf(mt, s[e]);
     mt = pl_half_max(mt) * sinv;
-    const float m_new = fmaxf(m_run, mt);
+    const float m_new = attn_lazy_max(m_run, mt);      // (= max(m_run, mt) up to the margin: jv_device.h)
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float lt = 0.f;
 #pragma unroll

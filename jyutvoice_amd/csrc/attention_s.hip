@@ -14,7 +14,8 @@
 // MFMAs of two neighbouring tiles and the softmax of the one between them are independent by construction, and
 // sched_group_barrier interleaves them one MFMA to four vector instructions.
 // Arithmetic: attention_pl.hip's, term for term (32x32x16 MFMAs, the same scales, base-2 softmax on raw v_exp_f32, P kept as
-// p * 2^10, products hh' + hl' + lh' smallest first); only the row sum is kept per lane-half until the end.
+// p * 2^10, products hh' + hl' + lh' smallest first, the same lazy reference maximum, every sum in the same order): the two
+// forms agree bit for bit, so an utterance's mel does not depend on which of them its batch size selects.
 #include <math.h>
 #include <stdlib.h>
 
@@ -37,7 +38,6 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int AS_PLANE = 32 * 128;                 // one plane of a 32-key tile: 128 bytes (64 d) per key
 constexpr int AS_STAGE = 4 * AS_PLANE;             // K h, K l, V h, V l
 constexpr int AS_NW = 2;
-constexpr float AS_LAZY = 4.0f;              // the softmax reference maximum moves only past this margin (base-2 units)
 
 // LDS slot keys: attention_pl.hip's (K read by rows with ds_read_b128, V transposed with ds_read_b64_tr_b16)
 __device__ __forceinline__ int ask_swz(int key) { return (key >> 1) & 7; }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
     }
   }
 
-  float m_run[QT], l_run[QT];      // l_run: this lane-half's keys only (the two halves are added at the end)
+  float m_run[QT], l_run[QT];
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     m_run[t] = -INFINITY;
@@ -343,16 +343,14 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
         else as_mfma_o<2 * t + db, F>(P[0]);                              // V high x P high
       };
       // micro-step I of tile t's softmax: s -> P planes (B operand of PV) and the running statistics.
-      // LAZY reference maximum: the exponent's reference m_run[t] moves only when the tile's maximum exceeds it by more than
-      // AS_LAZY (base-2 units), so P = p 2^10 can reach 2^(10 + AS_LAZY) = 2^14 < 65504 and O is rescaled a few times per
-      // head instead of in nearly every tile (a record high among 32 queries x 10 tiles is the rule, one 16x higher is not).
-      // Exact in exact arithmetic (the reference cancels in O / l); in fp32 it moves the rounding of p by < 1 ulp.
+      // The reference maximum is lazy (attn_lazy_max, jv_device.h) and every sum is formed in attention_pl.hip's order (keys
+      // of the lane in sequence, the two lane halves per tile, l = l alpha + that): the two forms agree bit for bit.
       auto smx = [&](auto ic, const int t) {
         constexpr int I = decltype(ic)::value;
         (void)w, (void)pb, (void)m_run, (void)l_run, (void)sinv, (void)len, (void)k0, (void)half;
         f32x16& x = s[t & 1];
         auto ex = [&](const int e) { x[e] = __builtin_amdgcn_exp2f(fmaf(x[e], sinv, w.bias)); };      // 12 issue cycles
-        auto add2 = [&](const int j) { w.lt = j ? w.lt + (x[2 * j] + x[2 * j + 1]) : x[0] + x[1]; };  // 8
+        auto add2 = [&](const int j) { w.lt = j ? (w.lt + x[2 * j]) + x[2 * j + 1] : (0.f + x[0]) + x[1]; };  // 8
         auto split = [&](const int j) {                                                                // 16-18
           const int st = j >> 2, e = j & 3;
           const Split2 sp = split2h_pair(x[8 * st + 2 * e], x[8 * st + 2 * e + 1]);
@@ -377,7 +375,7 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
           const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(w.mt), __float_as_uint(w.mt), false, false);
           w.mt = as_max3(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[1])) * sinv;
         } else if constexpr (I == 3) {
-          const float m_new = w.mt > m_run[t] + AS_LAZY ? w.mt : m_run[t];      // (m_run = -inf at the first tile: always moves)
+          const float m_new = attn_lazy_max(m_run[t], w.mt);      // (m_run = -inf at the first tile: always moves)
           w.dm = m_run[t] - m_new;
           w.bias = 10.f - m_new;      // p * 2^10 (cancels in 1 / l)
           m_run[t] = m_new;
@@ -395,7 +393,7 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
           add2(I - 12);
         } else {
           split(7);
-          l_run[t] = l_run[t] * w.alpha + w.lt;
+          l_run[t] = l_run[t] * w.alpha + as_half_sum(w.lt);
         }
       };
 
@@ -467,7 +465,7 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
     if (qbase >= p.L) return;      // (wave-uniform)
     float o[32];      // this lane's 32 values of query tile T: o[16 db + e]
     as_for<32>([&](auto ec) { o[decltype(ec)::value] = as_agpr<AS_O + 32 * T + decltype(ec)::value>(); });
-    const float l = as_half_sum(l_run[T]);
+    const float l = l_run[T];
     const float inv = l > 0.f ? (1.0f / vsc) / l : 0.f;
     if (p.out2) {
       const float sc = inv * p.out2_scale;

@@ -155,4 +155,12 @@ __device__ __forceinline__ Split2 split2h_pair(const float x0, const float x1) {
   return {__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, l)};
 }
 
+// Attention's running softmax (attention_pl.hip, attention_s.hip -- the same rule in both, so an utterance's result does not
+// depend on which of them its batch selects): the exponent's reference maximum moves only when a key tile's maximum exceeds it
+// by more than ATTN_LAZY (base-2 units).  P = p 2^10 can then reach 2^(10 + ATTN_LAZY) = 2^14 < 65504, and the accumulated
+// output is rescaled a few times per head instead of in nearly every tile (a record high among a tile's queries is the rule,
+// one 16x higher is not).  Exact in exact arithmetic: the reference cancels in O / l.
+constexpr float ATTN_LAZY = 4.0f;
+__device__ __forceinline__ float attn_lazy_max(const float m_run, const float mt) { return mt > m_run + ATTN_LAZY ? mt : m_run; }
+
 }  // namespace jv
