@@ -310,6 +310,54 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
 #pragma unroll
     for (int st = 0; st < 4; ++st) ql[t & 1][st] = *reinterpret_cast<const u32x4*>(qlo + (t * 4 + st) * 1024);
   };
+  // ---- result of query tile T: O / l as the output projection's operand (fp16 planes; fp32 rows without out2), transposed
+  // through an 8 KB LDS patch [2 planes][32 queries][128 B] so that the stores are whole 128-byte rows.  Called from inside the
+  // LAST key tile as soon as a tile's PV product is complete (after slot T + 1), through the ring stage no DMA will write
+  // again: the 40 MB of output leave under the remaining tiles' arithmetic instead of in one burst after it.
+  const float vsc = p.v_scale;
+  auto write_tile = [&](auto tc, unsigned char* const so) __attribute__((always_inline)) {
+    constexpr int T = decltype(tc)::value;
+    (void)vsc, (void)l_run, (void)rowbase, (void)h;
+    // (everything below is invariant over the key loop this is called from: made opaque, or the compiler hoists ~70 address
+    //  and predicate registers out of the loop and parks them in AGPRs -- the ones this kernel owns)
+    int q0l = q0, lane = tid & 63;
+    asm volatile("" : "+v"(q0l), "+v"(lane));
+    const int r32 = lane & 31, half = lane >> 5;
+    const int qbase = q0l + 32 * T;
+    if (qbase >= p.L) return;      // (wave-uniform)
+    asm volatile("s_nop 15\n\ts_nop 15");      // the tile's last PV MFMA may have been issued one instruction ago
+    const float l = l_run[T];
+    const float inv = l > 0.f ? (1.0f / vsc) / l : 0.f;
+    if (p.out2) {
+      const float sc = inv * p.out2_scale;
+      as_for<8>([&](auto gc) {      // four values at a time: the call sites sit inside the key loop, where registers are scarce
+        constexpr int db = decltype(gc)::value >> 2, g = decltype(gc)::value & 3, R = AS_O + 32 * T + 16 * db + 4 * g;
+        const Split2 a0 = split2h_pair(as_agpr<R>() * sc, as_agpr<R + 1>() * sc);
+        const Split2 a1 = split2h_pair(as_agpr<R + 2>() * sc, as_agpr<R + 3>() * sc);
+        const int d = db * 32 + 8 * g + 4 * half;      // 4 consecutive d: 8 bytes
+        unsigned char* dp = so + r32 * 128 + d * 2;
+        *reinterpret_cast<u32x2*>(dp) = u32x2{a0.h, a1.h};
+        *reinterpret_cast<u32x2*>(dp + 32 * 128) = u32x2{a0.l, a1.l};
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (a wave's LDS accesses execute in order)
+      // 8 lanes per row of 128 B, 8 rows per instruction: 2 planes x 32 rows = 8 instructions
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int pl = it >> 2, qrow = (it & 3) * 8 + (lane >> 3), piece = lane & 7;
+        const int qi = qbase + qrow;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(so + (pl * 32 + qrow) * 128 + piece * 16);
+        if (qi < p.L) *(__attribute__((address_space(1))) u32x4*)(p.out2 + (long)pl * p.out2_plane + (rowbase + qi) * p.ldo + h * 64 + piece * 8) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the patch is rewritten by the next tile
+    } else {
+      const int qi = qbase + r32;
+      as_for<8>([&](auto gc) {
+        constexpr int db = decltype(gc)::value >> 2, g = decltype(gc)::value & 3, R = AS_O + 32 * T + 16 * db + 4 * g;
+        const f32x4 a = {as_agpr<R>() * inv, as_agpr<R + 1>() * inv, as_agpr<R + 2>() * inv, as_agpr<R + 3>() * inv};
+        if (qi < p.L) *(__attribute__((address_space(1))) f32x4*)(p.out + (rowbase + qi) * p.ldo + h * 64 + 4 * half + 32 * db + 8 * g) = a;
+      });
+    }
+  };
   const bool work = active && EXPER != 2;
   if (work) load_ql(0);
   for (int kt = 0; kt < nkt; ++kt) {
@@ -426,6 +474,10 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
           as_agpr_scale16<AS_O + 32 * T>(w.alpha);      // (between slots: O[T] is next touched by PV(T), 12 MFMAs on)
           as_agpr_scale16<AS_O + 32 * T + 16>(w.alpha);
           AS_FENCE();
+          if constexpr (EDGE && T > 0) {      // tile T - 1 is complete: out it goes
+            write_tile(std::integral_constant<int, T - 1>{}, lds + ((kt + 1) % NST) * AS_STAGE + wave * (2 * 32 * 128));
+            AS_FENCE();
+          }
           stamp(2 + T);
         });
       }
@@ -439,6 +491,7 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
       if (work) {      // ---- tail: the PV product of the last tile
         as_for<12>([&](auto ic) { pv_mfma(ic, std::integral_constant<int, QT - 1>{}); });
         AS_FENCE();
+        if constexpr (EDGE) write_tile(std::integral_constant<int, QT - 1>{}, lds + ((kt + 1) % NST) * AS_STAGE + wave * (2 * 32 * 128));
       }
       stamp(8);
       if constexpr (!EDGE) {
@@ -452,59 +505,19 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
     if (kt + 1 < nkt) key_tile(std::false_type{});
     else key_tile(std::true_type{});
   }
-  asm volatile("s_nop 15\n\ts_nop 15");      // the last PV MFMA before the epilogue's reads of O
-
-  // ---- result: O / l as the output projection's operand (fp16 planes), each wave through its own 8 KB patch of the idle ring
-  as_lds_barrier();      // both waves are done with the ring
-  if (!active) return;
-  unsigned char* const so = lds + wave * (2 * 32 * 128);      // [2 planes][32 queries][128 B]
-  const float vsc = p.v_scale;
-  as_for<QT>([&](auto tc) {
-    constexpr int T = decltype(tc)::value;
-    const int qbase = q0 + 32 * T;
-    if (qbase >= p.L) return;      // (wave-uniform)
-    float o[32];      // this lane's 32 values of query tile T: o[16 db + e]
-    as_for<32>([&](auto ec) { o[decltype(ec)::value] = as_agpr<AS_O + 32 * T + decltype(ec)::value>(); });
-    const float l = l_run[T];
-    const float inv = l > 0.f ? (1.0f / vsc) / l : 0.f;
-    if (p.out2) {
-      const float sc = inv * p.out2_scale;
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const float* const v = o + 16 * db + 4 * g;
-          const Split2 a0 = split2h_pair(v[0] * sc, v[1] * sc);
-          const Split2 a1 = split2h_pair(v[2] * sc, v[3] * sc);
-          const int d = db * 32 + 8 * g + 4 * half;      // 4 consecutive d: 8 bytes
-          unsigned char* dp = so + r32 * 128 + d * 2;
-          *reinterpret_cast<u32x2*>(dp) = u32x2{a0.h, a1.h};
-          *reinterpret_cast<u32x2*>(dp + 32 * 128) = u32x2{a0.l, a1.l};
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (a wave's LDS accesses execute in order)
-      // 8 lanes per row of 128 B, 8 rows per instruction: 2 planes x 32 rows = 8 instructions
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int pl = it >> 2, qrow = (it & 3) * 8 + (lane >> 3), piece = lane & 7;
-        const int qi = qbase + qrow;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(so + (pl * 32 + qrow) * 128 + piece * 16);
-        if (qi < p.L) *(__attribute__((address_space(1))) u32x4*)(p.out2 + (long)pl * p.out2_plane + (rowbase + qi) * p.ldo + h * 64 + piece * 8) = v;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the patch is rewritten by the next tile
-    } else {
-      const int qi = qbase + r32;
-      if (qi < p.L) {
-        float* dp = p.out + (rowbase + qi) * p.ldo + h * 64 + 4 * half;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 a = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
-          const f32x4 c = {o[16 + 4 * g] * inv, o[16 + 4 * g + 1] * inv, o[16 + 4 * g + 2] * inv, o[16 + 4 * g + 3] * inv};
-          *(__attribute__((address_space(1))) f32x4*)(dp + 8 * g) = a;
-          *(__attribute__((address_space(1))) f32x4*)(dp + 32 + 8 * g) = c;
-        }
+  if (nkt == 0 && active) {      // an utterance without keys: zeros
+    for (int r = lane >> 3; r < QW; r += 8) {
+      const int qi = q0 + r, piece = lane & 7;
+      if (qi >= p.L) break;
+      if (p.out2) {
+        for (int pl = 0; pl < 2; ++pl)
+          *(__attribute__((address_space(1))) u32x4*)(p.out2 + (long)pl * p.out2_plane + (rowbase + qi) * p.ldo + h * 64 + piece * 8) = u32x4{0u, 0u, 0u, 0u};
+      } else {
+        for (int c = 0; c < 2; ++c)
+          *(__attribute__((address_space(1))) f32x4*)(p.out + (rowbase + qi) * p.ldo + h * 64 + piece * 8 + 4 * c) = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-  });
+  }
   stamp(10);
 #ifdef JV_TUNING
   if (EXPER == 3 && blockIdx.x == 0 && threadIdx.x == 0)
