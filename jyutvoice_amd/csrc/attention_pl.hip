@@ -259,8 +259,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (NST == 2 ? 4 : 3)) void att
           const f32x16& o = db ? o1 : o0;
           const Split2 a0 = split2h_pair(o[4 * g] * sc, o[4 * g + 1] * sc);
           const Split2 a1 = split2h_pair(o[4 * g + 2] * sc, o[4 * g + 3] * sc);
-          const int d = db * 32 + 8 * g + 4 * half;      // 4 consecutive d: 8 bytes
-          unsigned char* dstp = so + (wave * 32 + r32) * 128 + d * 2;
+          // d = 32 db + 8 g + 4 half .. + 3: 8 bytes, half of 16-byte chunk 4 db + g of the row; chunks XOR-keyed by the row
+          // (unkeyed the 32 rows of a store meet 16 lanes per bank pair: attention_s.hip, profiles/r03_pmc_bench.md)
+          unsigned char* dstp = so + (wave * 32 + r32) * 128 + (((4 * db + g) ^ ((r32 >> 1) & 7)) << 4) + 8 * half;
           *reinterpret_cast<u32x2*>(dstp) = u32x2{a0.h, a1.h};
           *reinterpret_cast<u32x2*>(dstp + 32 * NW * 128) = u32x2{a0.l, a1.l};
         }
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (NST == 2 ? 4 : 3)) void att
       const int qrow = rem >> 3, piece = rem & 7;
       const int qi = qt * 32 * NW + qrow;
       if (qi < p.L) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(so + (pl * 32 * NW + qrow) * 128 + piece * 16);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(so + (pl * 32 * NW + qrow) * 128 + ((piece ^ ((qrow >> 1) & 7)) << 4));
         *reinterpret_cast<u32x4*>(p.out2 + (long)pl * p.out2_plane + (rowbase + qi) * p.ldo + h * 64 + piece * 8) = v;
       }
     }

@@ -334,8 +334,10 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
         constexpr int db = decltype(gc)::value >> 2, g = decltype(gc)::value & 3, R = AS_O + 32 * T + 16 * db + 4 * g;
         const Split2 a0 = split2h_pair(as_agpr<R>() * sc, as_agpr<R + 1>() * sc);
         const Split2 a1 = split2h_pair(as_agpr<R + 2>() * sc, as_agpr<R + 3>() * sc);
-        const int d = db * 32 + 8 * g + 4 * half;      // 4 consecutive d: 8 bytes
-        unsigned char* dp = so + r32 * 128 + d * 2;
+        // d = 32 db + 8 g + 4 half .. + 3: 8 bytes, the half of 16-byte chunk 4 db + g of the query's row; chunks XOR-keyed by
+        // the row (ask_swz) -- unkeyed, the 32 rows of a store put 16 lanes on each bank pair (PMC: 4.9 M conflict cycles of
+        // 7.0 M LDS-active per launch), keyed two
+        unsigned char* dp = so + r32 * 128 + (((4 * db + g) ^ ask_swz(r32)) << 4) + 8 * half;
         *reinterpret_cast<u32x2*>(dp) = u32x2{a0.h, a1.h};
         *reinterpret_cast<u32x2*>(dp + 32 * 128) = u32x2{a0.l, a1.l};
       });
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
       for (int it = 0; it < 8; ++it) {
         const int pl = it >> 2, qrow = (it & 3) * 8 + (lane >> 3), piece = lane & 7;
         const int qi = qbase + qrow;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(so + (pl * 32 + qrow) * 128 + piece * 16);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(so + (pl * 32 + qrow) * 128 + ((piece ^ ask_swz(qrow)) << 4));
         if (qi < p.L) *(__attribute__((address_space(1))) u32x4*)(p.out2 + (long)pl * p.out2_plane + (rowbase + qi) * p.ldo + h * 64 + piece * 8) = v;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the patch is rewritten by the next tile

@@ -85,7 +85,8 @@ for L in ((int(os.environ["JV_ATTN_L"]),) if os.environ.get("JV_ATTN_L") else (3
     lens = torch.full((B,), int(os.environ.get("JV_ATTN_LEN", L)), dtype=torch.int32, device=dev)      # JV_ATTN_LEN: valid keys (fewer key tiles, same queries)
     if os.environ.get("JV_OP_ATTN_PL"):      # K / V as planes by LDS-DMA (attention_pl.hip)
         bounds = tuple(8.0 * float(qkv[:, o:o + 512].abs().max()) for o in (0, 512, 1024))
-        t = timeit(lambda: op_attention_planes(qkv, lens, B, 4, S, L, bounds))
+        po = bool(os.environ.get("JV_ATTN_PLANES_OUT"))      # the result as fp16 planes, as the pipeline takes it (timing includes the test-side conversion: read the kernel from a trace)
+        t = timeit(lambda: op_attention_planes(qkv, lens, B, 4, S, L, bounds, planes_out=po))
     elif os.environ.get("JV_OP_H3"):      # fp16x3 attention with bounds as a load-time L1-norm bound would give them
         bounds = tuple(8.0 * float(qkv[:, o:o + 512].abs().max()) for o in (0, 512, 1024))
         t = timeit(lambda: op_attention_h3(qkv, lens, B, 4, S, L, bounds))
