@@ -456,11 +456,21 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
     asrc[i] = p.A + arc[i] * p.lda + 4 * c4;
     adst[i] = r < WR ? r * 64 + ((((c4 >> 1) ^ rg_key(r)) << 4) | ((c4 & 1) << 3)) : -1;
   }
+  // The window rows of the next chunk travel in registers for a chunk's worth of steps.  Loaded by asm like the weight
+  // fragments: as plain loads the compiler put its own s_waitcnt vmcnt(0) in front of store_A -- it cannot see the weight
+  // loads issued since, so once per chunk that wait drained the fragments in flight (stamps: 1340 cycles per step against
+  // the 900 of the same loop in rowblock_kernel.h).  The steps' counted waits already cover these loads (they are older
+  // than the newest NWL fragment loads at the wait of step (c, 2)); landed_a() tells the compiler so.
   rg_f32x4 pa[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) pa[i] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
   auto load_A = [&](int c) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)      // explicitly GLOBAL loads (a generic pointer would make them flat_load: lgkmcnt as well, out of order)
-      pa[i] = *(const __attribute__((address_space(1))) rg_f32x4*)(asrc[i] + c * 32);
+    for (int i = 0; i < NI; ++i) asm volatile("global_load_dwordx4 %0, %1, off ; window rows" : "+v"(pa[i]) : "v"(asrc[i] + c * 32) : "memory");
+  };
+  auto landed_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(pa[i])::"memory");
   };
   auto store_A = [&](int buf) {
     unsigned char* const base = rc_lds + A_OFF + buf * A_BUF;
@@ -522,6 +532,8 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
     bb = *reinterpret_cast<const rg_f32x4*>(p.ln_b + 4 * lane);
   }
   stamp();      // 1: row facts and staging addresses set up
+  rg_wait_vmcnt<0>();      // the first window's rows (and the first fragments, needed two lines down anyway)
+  landed_a();
   store_A(0);
   if (NCH > 1) load_A(1);
   // both steps' fragments (and everything older) have landed once only the A loads of chunk 1 are outstanding
@@ -540,7 +552,11 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
     constexpr int par = decltype(par_tag)::value;
     if (j == 0) {
       rg_lds_barrier();      // every thread's plane stores of this chunk's window are complete; the other buffer is free
-      if (c + 1 < NCH) store_A((c + 1) & 1);      // its registers were loaded a chunk ago
+      if (c + 1 < NCH) {      // its registers were loaded a chunk ago and waited for at step (c - 1, 2) ...
+        if (c == 0) rg_wait_vmcnt<0>();      // ... except chunk 1's, issued just ahead of the loop (nothing else is in flight yet)
+        landed_a();
+        store_A((c + 1) & 1);
+      }
     }
     const unsigned char* const sa = rc_lds + A_OFF + (c & 1) * A_BUF;
     rg_u32x4 af[RT][2];

@@ -50,7 +50,8 @@ def check_kernel(name, body):
         if t.startswith(";;#ASMEND"):
             in_asm = False
             continue
-        if in_asm and t.startswith("global_load_dwordx4"):
+        if in_asm and t.startswith("global_load_dwordx4") and "window rows" not in t:      # (rowconv's A-window loads are asm too:
+            #  ordinary values once landed_a() has passed, read by the staging code -- not part of the fragment buffer)
             dest = t.split(None, 1)[1].split(",")[0]
             loads.append((i, regs_of(dest)))
     if not loads:
