@@ -106,6 +106,8 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   c.rg_ff1 = getenv("JV_TILE_FF1") == nullptr;
   c.no_ffn_fuse = getenv("JV_NO_FFN_FUSE") != nullptr;
   c.no_block_fuse = getenv("JV_NO_BLOCK_FUSE") != nullptr;
+  c.no_qkv_split = getenv("JV_NO_QKV_SPLIT") != nullptr;
+  c.no_ln_fold = getenv("JV_NO_LN_FOLD") != nullptr;
   c.no_attn_planes = getenv("JV_NO_ATTN_PLANES") != nullptr;
   c.no_hiftconv = getenv("JV_NO_HIFTCONV") != nullptr;
   c.attn_rows = getenv("JV_ATTN_ROWS") != nullptr;

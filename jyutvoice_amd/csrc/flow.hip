@@ -21,6 +21,7 @@ namespace jv {
 
 int rowgemm(const RowGemmArgs& a, int epi, hipStream_t st);   // rowgemm.hip
 int rowconv(const RowConvArgs& a, hipStream_t st);
+bool rowconv_w_direct(const RowConvArgs& a);      // rowgemm.hip
 int rowffn(const RowFfnArgs& a, hipStream_t st);
 int rowblock(const RowBlockArgs& a, bool qkv, hipStream_t st);   // rowblock.hip
 int rowgemm_tile(int M);
@@ -237,7 +238,11 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   // A causal k = 3 convolution of a trunk buffer: on the row-owning kernel (rowconv_kernel.h: LayerNorm / Mish / mask / time
   // embedding / residual in its epilogue, no ln_epilogue_rows pass) when the batch fills the chip, else on the tile kernels
   const bool use_rc = !c.exact_range && !c.no_rowgemm && rowgemm_tile((int)g.M) > 0;
-  auto conv3 = [&](ConvGemmArgs& a, const GemmW& m) -> int {
+  // `follow` / `followed`: the transformer block whose norm1 reads this convolution's output (a resnet's second
+  // convolution, in place in the trunk): on the W-direct row-owning kernel its LayerNorm planes are written by the
+  // convolution's own epilogue (RowConvArgs::ln2_out) and *followed is set; every other route leaves it to the caller
+  auto conv3 = [&](ConvGemmArgs& a, const GemmW& m, const BtbW* follow = nullptr, bool* followed = nullptr) -> int {
+    if (followed) *followed = false;
     if (splittable(a) && a.N == 256 && !a.res2) return splitk(a, nullptr, nullptr);
     if (!use_rc || !a.amax_in || !m.w2 || a.ntaps != 3 || a.tap_row0 != -2 || a.N != 256 || a.ldo != 256 && a.ldo != 512)
       return conv_gemm(a, 1, st);
@@ -252,6 +257,12 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     r.rowvec = a.rowvec; r.rowvec_ld = a.rowvec_ld; r.res = a.res1; r.ldr = a.ldr1;
     r.amax_out = a.amax_out; r.row_mask = w.rowmask;
     r.alg_rows = a.alg_rows;
+    if (follow && followed && !c.no_ln_fold && a.out == w.h && a.ldo == 256 && follow->qkv.w2 && follow->qkv.a_scale > 0.f &&
+        rowconv_w_direct(r)) {
+      r.ln2_out = reinterpret_cast<unsigned short*>(w.ln); r.ln2_plane = (long)w.rows_alloc * 256;
+      r.ln2_g = follow->n1.g; r.ln2_b = follow->n1.b; r.ln2_scale = follow->qkv.a_scale;
+      *followed = true;
+    }
     if (tuning_env("JV_RB_STAMPS")) {
       if (!w.rc_stamps) JV_TRY(ws_alloc(c, 1024 * 8 * sizeof(unsigned long long), reinterpret_cast<void**>(&w.rc_stamps)));
       r.stamps = w.rc_stamps;
@@ -267,7 +278,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     ConvStackScope() : on(prof_on()) { if (on) prof_group("flow_conv_stack"); }
     ~ConvStackScope() { if (on) prof_group(nullptr); }
   };
-  auto resnet = [&](int i, const float* in, int ldin, float* out, int ldo) -> int {
+  auto resnet = [&](int i, const float* in, int ldin, float* out, int ldo, const BtbW* follow = nullptr, bool* followed = nullptr) -> int {
     ConvStackScope scope;
     const ResnetW& r = e.res[i];
     ConvGemmArgs a = base_args(g, in, ldin, r.block1, w.h2, 256);
@@ -289,7 +300,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.res1 = w.res; a.ldr1 = 256;
     h3m(a, r.block2);
     track(a);      // -> h
-    return conv3(a, r.block2);
+    return conv3(a, r.block2, follow, followed);
   };
   // BasicTransformerBlock (transformer.py:355-443): h -> h, last GEMM may retarget its output
   // the four linears of a block run fp16x3 when registry.hip proved their input range (GemmW::a_scale)
@@ -380,6 +391,18 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   auto rg_track = [&](RowGemmArgs& a) {
     a.amax_out = slots_of(a.out); a.row_slot = w.row_sample; a.row_mask = w.rowmask;
   };
+  // Few row tiles (3 - 10 utterances of 300 frames: 64 - 170 workgroups of 32 rows on 256 CUs): a workgroup's length is set
+  // by the weights it streams through its CU's L2 port, not by its MFMAs, and a third of the fused block's steps are the
+  // next block's q | k | v, whose six 256-column chunks need nothing from each other.  There the q | k | v phase leaves the
+  // fused launch: phase B's epilogue writes the LayerNorm1 planes to HBM and rowgemm_wa runs with its chunks dealt over
+  // qkv_split workgroups per row tile.  Same K order, same epilogue expressions: the same bits as the fused launch
+  // (tests/test_gpu_pipeline.py::test_split_qkv_equals_fused_block).  JV_NO_QKV_SPLIT=1: fused at every batch size.
+  int qkv_split = 1;
+  if (use_rg && !c.no_qkv_split) {
+    const int rt = rowgemm_tile((int)g.M);
+    const long wgs = rt > 0 ? cdivl(g.M, 16 * rt) : 0;
+    if (wgs > 0 && wgs <= 170) qkv_split = wgs <= 85 ? 6 : 3;
+  }
   // `qkv_ready`: the previous block's fused launch has already produced this block's q | k | v (rowblock_kernel.h);
   // `qkv_next` (out): this block's launch produced the next block's
   auto ffn_fusable = [&](const BtbW& b) {
@@ -401,6 +424,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     at.out2 = reinterpret_cast<unsigned short*>(w.att); at.out2_plane = R * 512; at.out2_scale = b.out.a_scale;
     if (!c.no_attn_planes) {
       if (!qkv_ready) {
+        a.nsplit = qkv_split;
         a.out = w.qkv; a.ldo = 512;
         a.out2 = kv2; a.out2_plane = R * 1024; a.ldo2 = 1024; a.out2_scale = b.k_scale; a.out2_scale2 = b.v_scale;
         JV_TRY(rowgemm(a, RG_QKV, st));
@@ -429,11 +453,18 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
       f.out = out; f.ldo = ldo;
       f.amax_h = slots_of(h); f.amax_out = slots_of(out); f.row_slot = w.row_sample; f.row_mask = w.rowmask;
       f.alg_rows = (long)g.B2 * g.T;
-      const bool qkv = next && out == h;
+      const bool follows = next && out == h;
+      const bool qkv = follows && qkv_split <= 1;
+      if (follows) {
+        f.ln1_g = next->n1.g; f.ln1_b = next->n1.b; f.a_scale_q = next->qkv.a_scale;
+      }
       if (qkv) {
-        f.ln1_g = next->n1.g; f.ln1_b = next->n1.b;
-        f.Wqf = next->qkv.wf; f.wqf_plane = (long)next->qkv.N * next->qkv.Cin; f.csq = next->qkv.colscale; f.a_scale_q = next->qkv.a_scale;
+        f.Wqf = next->qkv.wf; f.wqf_plane = (long)next->qkv.N * next->qkv.Cin; f.csq = next->qkv.colscale;
         f.q = w.qkv; f.kv2 = kv2; f.kv2_plane = R * 1024; f.k_scale = next->k_scale; f.v_scale = next->v_scale;
+      } else if (follows) {
+        // few row tiles: the next block's LayerNorm1 planes leave through HBM and its q | k | v runs as its own launch with
+        // the column chunks dealt over the idle CUs (qkv_split, above)
+        f.ln_out = reinterpret_cast<unsigned short*>(w.ln); f.ln_out_plane = R * 256;
       }
       *qkv_next = qkv;
       if (tuning_env("JV_RB_STAMPS")) {
@@ -492,21 +523,29 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     return rowgemm(a, RG_RES, st);
   };
   // the four blocks of a stage; the last one may retarget its output (skip / concat buffer)
-  auto stage_blocks = [&](const BtbW* blk, float* h, float* last_out, int last_ldo) -> int {
+  auto stage_all_rg = [&](const BtbW* blk) {
     bool all = use_rg;
     for (int j = 0; j < EST_NBLK; ++j) all = all && rg_ok(blk[j]);
+    return all;
+  };
+  // `ln_first`: the first block's norm1 planes are already in w.ln (written by the resnet's last convolution)
+  auto stage_blocks = [&](const BtbW* blk, float* h, float* last_out, int last_ldo, bool ln_first = false) -> int {
+    const bool all = stage_all_rg(blk);
     bool qkv_ready = false;
     for (int j = 0; j < EST_NBLK; ++j) {
       const bool last = j == EST_NBLK - 1;
-      if (all) JV_TRY(btb_rg(blk[j], last ? nullptr : &blk[j + 1], j > 0, qkv_ready, &qkv_ready, h, last ? last_out : h, last ? last_ldo : 256));
+      if (all) JV_TRY(btb_rg(blk[j], last ? nullptr : &blk[j + 1], j > 0 || ln_first, qkv_ready, &qkv_ready, h, last ? last_out : h, last ? last_ldo : 256));
       else JV_TRY(btb(blk[j], last ? nullptr : &blk[j + 1], j > 0, h, last ? last_out : h, last ? last_ldo : 256));
     }
     return JV_OK;
   };
 
   // down: resnet -> 4 blocks (result doubles as the skip) -> causal conv
-  JV_TRY(resnet(0, w.xin, 320, w.h, 256));
-  JV_TRY(stage_blocks(e.blk[0], w.h, skip, 512));
+  // (a stage on the row-owning kernels takes its first norm1 from the resnet's last convolution)
+  bool lnf = false;
+  auto follow_of = [&](const BtbW* blk) -> const BtbW* { return stage_all_rg(blk) ? blk : nullptr; };
+  JV_TRY(resnet(0, w.xin, 320, w.h, 256, follow_of(e.blk[0]), &lnf));
+  JV_TRY(stage_blocks(e.blk[0], w.h, skip, 512, lnf));
   {
     ConvStackScope scope;
     ConvGemmArgs a = base_args(g, skip, 512, e.down_conv, w.h, 256);
@@ -517,12 +556,12 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   }
   // mid x12; the last block writes straight into columns [0,256) of the concat buffer
   for (int i = 1; i <= EST_NMID; ++i) {
-    JV_TRY(resnet(i, w.h, 256, w.h, 256));
-    JV_TRY(stage_blocks(e.blk[i], w.h, i == EST_NMID ? w.cat : w.h, i == EST_NMID ? 512 : 256));
+    JV_TRY(resnet(i, w.h, 256, w.h, 256, follow_of(e.blk[i]), &lnf));
+    JV_TRY(stage_blocks(e.blk[i], w.h, i == EST_NMID ? w.cat : w.h, i == EST_NMID ? 512 : 256, lnf));
   }
   // up: resnet(cat[x, skip]) -> 4 blocks -> causal conv -> final block -> 1x1 projection
-  JV_TRY(resnet(EST_NRES - 1, w.cat, 512, w.h, 256));
-  JV_TRY(stage_blocks(e.blk[EST_NRES - 1], w.h, w.h, 256));
+  JV_TRY(resnet(EST_NRES - 1, w.cat, 512, w.h, 256, follow_of(e.blk[EST_NRES - 1]), &lnf));
+  JV_TRY(stage_blocks(e.blk[EST_NRES - 1], w.h, w.h, 256, lnf));
   {
     ConvStackScope scope;
     ConvGemmArgs a = base_args(g, w.h, 256, e.up_conv, w.h2, 256);

@@ -20,7 +20,9 @@ int rb_launch(const RowBlockArgs& a, hipStream_t st) {
   if (prof) prof_begin(st);
   hipLaunchKernelGGL((rowblock_kernel<RT, QKV>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rb_lds_bytes<RT>(), st, a);
   if (prof) {
-    static const std::string name = std::string("rowblock_h3<") + std::to_string(16 * RT) + "x256" + (QKV ? ",qkv>" : ">");
+    static const std::string name_plain = std::string("rowblock_h3<") + std::to_string(16 * RT) + "x256" + (QKV ? ",qkv>" : ">");
+    static const std::string name_ln = std::string("rowblock_h3<") + std::to_string(16 * RT) + "x256,ln>";
+    const std::string& name = (!QKV && a.ln_out) ? name_ln : name_plain;
     const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M);
     // algorithmic work: to_out (512 -> 256) + ff.net.0 (256 -> 1024) + ff.net.2 (1024 -> 256) (+ q|k|v: 256 -> 1536);
     // bytes: attention planes in (512 x 4 B per row), residual in, rows out (256 x 4 B each), the weights, (+ q|k|v out)
@@ -49,6 +51,8 @@ int rowblock(const RowBlockArgs& a, bool qkv, hipStream_t st) {
   if (qkv && (a.out != a.h || a.ldo != 256)) return fail(JV_ERR_ARG, "rowblock: the q|k|v phase follows a block that writes the trunk in place");
   if (qkv && (!a.Wqf || !a.csq || !(a.a_scale_q > 0.f) || !a.ln1_g || !a.ln1_b || !a.q || !a.kv2 || !(a.k_scale > 0.f) || !(a.v_scale > 0.f)))
     return fail(JV_ERR_ARG, "rowblock: the q|k|v phase needs LayerNorm1, fragment-order weights, scales, a q buffer and a K/V plane buffer");
+  if (!qkv && a.ln_out && (a.out != a.h || a.ldo != 256 || !a.ln1_g || !a.ln1_b || !(a.a_scale_q > 0.f) || a.ln_out_plane <= 0))
+    return fail(JV_ERR_ARG, "rowblock: LayerNorm1 planes to HBM need a block that writes the trunk in place, LayerNorm1 and its scale");
   int rt = rowgemm_tile(a.M);
   if (rt == 0) rt = 2;
   if (rt == 1) rt = 2;

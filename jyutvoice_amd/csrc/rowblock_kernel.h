@@ -69,6 +69,10 @@ struct RowBlockArgs {
   unsigned short* kv2;           // planes [2][rows][1024]: k * k_scale in columns 0..511, v * v_scale in 512..1023
   long kv2_plane;
   float k_scale, v_scale;
+  // ---- not QKV, a next block exists (mid-size batches, flow.hip `qkv_split`): LayerNorm1_next(out) still runs in phase B's
+  // epilogue and its planes go to HBM, [2][rows][256] at plane stride ln_out_plane, for a column-split q|k|v launch
+  unsigned short* ln_out;
+  long ln_out_plane;
   long alg_rows;
   unsigned long long* stamps;      // tuning aid (JV_RB_STAMPS, tuning builds): [workgroup][48] s_memtime at the phase boundaries
 };
@@ -353,7 +357,8 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   // the row pass shared by the two residual epilogues: rows [wave NRW, + NRW) of the tile, RT at a time, from the slab:
   //   v = slab * cs + bias + res -> dst rows (+ tracking); LN: LayerNorm_256(v) * sc -> fp16 planes into the operand image X
   auto row_pass = [&](const rg_f32x4 cs4, const rg_f32x4 b4, const rg_f32x4 (&rpre)[NRW], const RowFacts facts, float* dstp,
-                      const long ldd, float* amax, const bool ln, const rg_f32x4 gg, const rg_f32x4 bb, const float sc) {
+                      const long ldd, float* amax, const bool ln, const rg_f32x4 gg, const rg_f32x4 bb, const float sc,
+                      unsigned short* const gplanes) {      // gplanes: the LayerNorm planes to HBM as well (RowBlockArgs::ln_out)
     auto rows = [&](auto ps_tag) {
       constexpr int ps = decltype(ps_tag)::value;
       rg_f32x4 v[RT];
@@ -411,6 +416,13 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
           unsigned char* d = rg_lds + (lane >> 3) * STAGE + trow * 64 + (((((lane & 7) >> 1) ^ rg_key(trow))) << 4) + (lane & 1) * 8;
           *reinterpret_cast<rg_u32x2*>(d) = rg_u32x2{s0.h, s1.h};
           *reinterpret_cast<rg_u32x2*>(d + A_PLANE) = rg_u32x2{s0.l, s1.l};
+          if constexpr (!QKV) {
+            if (gplanes && ok[j]) {
+              unsigned short* const o2 = gplanes + (long)(drow0 + j) * 256 + lane4;
+              *(__attribute__((address_space(1))) rg_u32x2*)(o2) = rg_u32x2{s0.h, s1.h};
+              *(__attribute__((address_space(1))) rg_u32x2*)(o2 + p.ln_out_plane) = rg_u32x2{s0.l, s1.l};
+            }
+          }
         }
       }
     };
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
     rg_lds_barrier();
     xstamp();      // 20: slab written
     cs4 = cs4 * p.inv_a_scale_o;      // (first use of a loaded value: HERE, behind the barriers that hide the loads' ~2 k cycles, not in front of them)
-    row_pass(cs4, b4, rpre, facts_h, p.h, LDH, p.amax_h, true, gg, bb, p.a_scale1);
+    row_pass(cs4, b4, rpre, facts_h, p.h, LDH, p.amax_h, true, gg, bb, p.a_scale1, nullptr);
     xstamp();      // 21: row pass done (this wave)
     asm volatile("" ::"v"(warm2));      // (issued a whole row pass ago)
     rg_lds_barrier();      // X is complete, the slab has been read: the upper half is free for H
@@ -581,7 +593,8 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
     rg_f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (p.b2) b4 = *reinterpret_cast<const rg_f32x4*>(p.b2 + 4 * lane);
     rg_f32x4 gg = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (QKV) {
+    const bool ln_b = QKV || p.ln_out != nullptr;      // (not QKV: the planes go to HBM for a column-split q|k|v launch)
+    if (ln_b) {
       gg = *reinterpret_cast<const rg_f32x4*>(p.ln1_g + 4 * lane);
       bb = *reinterpret_cast<const rg_f32x4*>(p.ln1_b + 4 * lane);
     }
@@ -594,7 +607,8 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
     rg_lds_barrier();
     xstamp();      // 24: slab written
     cs4 = cs4 * p.inv_h_scale;
-    row_pass(cs4, b4, rpre, facts_o, p.out, QKV ? LDH : p.ldo, p.amax_out, QKV, gg, bb, QKV ? p.a_scale_q : 1.f);      // (q|k|v follows only where out is the trunk itself)
+    row_pass(cs4, b4, rpre, facts_o, p.out, QKV ? LDH : p.ldo, p.amax_out, ln_b, gg, bb, ln_b ? p.a_scale_q : 1.f,
+             QKV ? nullptr : p.ln_out);      // (q|k|v follows only where out is the trunk itself)
     xstamp();      // 25: row pass done
     if constexpr (QKV) rg_lds_barrier();      // X is complete, the slab has been read: the patches go over it
   }

@@ -45,6 +45,13 @@ struct RowConvArgs {
   long ldr;
   float* amax_out;                       // tracking of what is stored (rows with row_mask == 0 excluded)
   const unsigned char* row_mask;
+  // rowconv_wd_kernel: LayerNorm_256 of the STORED row (gain ln2_g, offset ln2_b, ln_eps), times ln2_scale, as fp16 planes
+  // [2][rows][256] at plane stride ln2_plane -- the norm1 of the transformer block that follows a resnet's second
+  // convolution (transformer.py:355-364), which was a launch of its own (layernorm256_planes) per stage
+  unsigned short* ln2_out;
+  long ln2_plane;
+  const float *ln2_g, *ln2_b;
+  float ln2_scale;
   long alg_rows;
   int ablate;      // tuning aid (JV_RG_ABLATE, tuning builds): 1 no weight DMA in the loop, 2 no LDS reads + MFMAs, 4 no waits / barriers,
                    // 8 no A staging in the loop, 16 no epilogue
@@ -676,6 +683,36 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
       for (int e = 0; e < 4; ++e) v[jj][e] = in.keep[jj] ? (mish ? mish_fast(v[jj][e]) : act_apply(v[jj][e], p.act)) : 0.f;
       v[jj] = (v[jj] + in.rv[jj]) + in.r[jj];
       if (in.ok[jj]) *reinterpret_cast<rg_f32x4*>(p.out + mrow * p.ldo + 4 * lane) = v[jj];
+    }
+    if (p.ln2_out) {      // (uniform) the following block's norm1 of the stored rows -> operand planes (rowblock_kernel.h's row pass)
+      float sum[RPW], sq[RPW];
+#pragma unroll
+      for (int jj = 0; jj < RPW; ++jj) sum[jj] = wave_sum((v[jj][0] + v[jj][1]) + (v[jj][2] + v[jj][3]));
+#pragma unroll
+      for (int jj = 0; jj < RPW; ++jj) {
+        const rg_f32x4 d = v[jj] - sum[jj] * (1.f / 256.f);
+        sq[jj] = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+      }
+      float var_l = sq[0];
+#pragma unroll
+      for (int jj = 1; jj < RPW; ++jj) var_l = lane == jj ? sq[jj] : var_l;
+      const float rstd_l = 1.0f / sqrtf(var_l * (1.f / 256.f) + p.ln_eps);
+      const rg_f32x4 g2 = *reinterpret_cast<const rg_f32x4*>(p.ln2_g + 4 * lane);
+      const rg_f32x4 b2 = *reinterpret_cast<const rg_f32x4*>(p.ln2_b + 4 * lane);
+#pragma unroll
+      for (int jj = 0; jj < RPW; ++jj) {
+        const long mrow = (long)m0 + wave * 2 * RT + ps * RT + jj;
+        const float mean = sum[jj] * (1.f / 256.f);
+        const float rstd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rstd_l), jj));
+        const rg_f32x4 y = (v[jj] - mean) * rstd * g2 + b2;
+        const Split2 s0 = split2h_pair(y[0] * p.ln2_scale, y[1] * p.ln2_scale);
+        const Split2 s1 = split2h_pair(y[2] * p.ln2_scale, y[3] * p.ln2_scale);
+        if (in.ok[jj]) {
+          unsigned short* const o2 = p.ln2_out + mrow * 256 + 4 * lane;
+          *reinterpret_cast<rg_u32x2*>(o2) = rg_u32x2{s0.h, s1.h};
+          *reinterpret_cast<rg_u32x2*>(o2 + p.ln2_plane) = rg_u32x2{s0.l, s1.l};
+        }
+      }
     }
     if (p.amax_out) {
 #pragma unroll

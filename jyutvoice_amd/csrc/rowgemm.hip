@@ -41,7 +41,9 @@ int rg_launch_wa(const RowGemmArgs& a, hipStream_t st) {
     JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_wa_kernel<RT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     raised[dev & 63] = lds;
   }
-  hipLaunchKernelGGL((rowgemm_wa_kernel<RT, EPI>), dim3(cdiv(a.M, 16 * RT)), dim3(512), lds, st, a);
+  const int nc = a.N >> 8;
+  const int ns = a.nsplit > 1 ? (a.nsplit < nc ? a.nsplit : nc) : 1;      // column chunks dealt over grid.y (RowGemmArgs::nsplit)
+  hipLaunchKernelGGL((rowgemm_wa_kernel<RT, EPI>), dim3(cdiv(a.M, 16 * RT), ns), dim3(512), lds, st, a);
   return JV_OK;
 }
 
@@ -129,6 +131,9 @@ int rowgemm_tile(int M) {
   return best;
 }
 
+// W-direct (rowconv_wd_kernel): fragment-order weights and an even number of 32-channel chunks
+bool rowconv_w_direct(const RowConvArgs& a) { return a.Wf && !((a.Cin >> 5) & 1) && !dyn_env("JV_RG_WLDS"); }
+
 namespace {
 template <int RT>
 int rc_launch(const RowConvArgs& a, hipStream_t st) {
@@ -141,7 +146,8 @@ int rc_launch(const RowConvArgs& a, hipStream_t st) {
     raised[dev & 63] = true;
   }
   static bool raised_wd[64] = {};
-  const bool wdir = a.Wf && !((a.Cin >> 5) & 1) && !dyn_env("JV_RG_WLDS");      // W-direct: an even number of 32-channel chunks
+  const bool wdir = rowconv_w_direct(a);
+  if (a.ln2_out && !wdir) return fail(JV_ERR_ARG, "rowconv: the following LayerNorm exists on the W-direct kernel only");
   if (wdir && !raised_wd[dev & 63]) {
     JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowconv_wd_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                rcw_lds_bytes<RT>()));
@@ -171,6 +177,8 @@ int rowconv(const RowConvArgs& a, hipStream_t st) {
   if ((a.Cin & 31) || a.Cin < 32 || (a.lda & 3) || (a.ldw & 7) || (a.ldo & 3) || (a.res && (a.ldr & 3)) || (a.rowvec && (a.rowvec_ld & 3)))
     return fail(JV_ERR_ARG, "rowconv: Cin % 32 == 0 and aligned strides required");
   if (a.ln && (!a.ln_g || !a.ln_b)) return fail(JV_ERR_ARG, "rowconv: LayerNorm needs gain and offset");
+  if (a.ln2_out && (!a.ln2_g || !a.ln2_b || !(a.ln2_scale > 0.f) || a.ln2_plane <= 0 || a.ldo != 256))
+    return fail(JV_ERR_ARG, "rowconv: the following LayerNorm needs gain, offset, a scale, a plane stride and 256-wide output rows");
   int rt = rowgemm_tile(a.M);
   if (rt == 0) rt = 2;
   switch (rt) {

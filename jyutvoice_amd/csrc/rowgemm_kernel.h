@@ -74,6 +74,7 @@ struct RowGemmArgs {
   const int* row_slot;
   const unsigned char* row_mask;
   long alg_rows;      // profiler: real frames
+  int nsplit;         // rowgemm_wa_kernel: the N / 256 column chunks are dealt to nsplit workgroups per row tile (grid.y); 0 / 1: one
   int ablate;         // tuning aid (JV_RG_ABLATE, tuning builds): 1 no loads in the loop, 2 no MFMAs, 4 no barrier/wait (LDS kernel),
                       // W-direct kernel also: 8 no LDS fragment reads, 16 no W loads, 32 no A DMA, 64 no row pass
 };
@@ -862,11 +863,16 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wa_kernel(const RowGemmArgs p)
   const int r16 = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.x * R;
   const int KS = p.K >> 5, NC = p.N >> 8;
-  const int total = KS * NC;
+  // Column split (RowGemmArgs::nsplit, grid.y): this workgroup owns the chunks [c0, c1) of its rows.  A batch of 3 - 10
+  // utterances makes fewer row tiles than the chip has CUs and every workgroup streams the whole weight matrix through its
+  // CU's 64 B / clk L2 port -- which, not the matrix pipe, then sets the launch's length (at RT = 2 a step's 32 KB of weights
+  // are 512 cycles against 384 of MFMA issue).  The chunks are independent given the rows' operand planes: dealt to the
+  // idle CUs, each workgroup streams its share only.  Same K order per output: the same bits.
+  const int c0 = (int)blockIdx.y * NC / (int)gridDim.y, c1 = ((int)blockIdx.y + 1) * NC / (int)gridDim.y;
   float* const slab = reinterpret_cast<float*>(rg_lds + KS * STAGE);
 
   float warm = 0.f;      // L2 warm-up of the weights (rowgemm_kernel)
-  {
+  if (gridDim.y == 1) {
     const long lpp = ((long)p.N * p.K * 2) >> 7;
     const int grp = blockIdx.x >> 3, ngrp = (gridDim.x + 7) >> 3;
     const long per = (2 * lpp + ngrp - 1) / ngrp;
@@ -902,8 +908,8 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wa_kernel(const RowGemmArgs p)
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) wbase[nt][pl] = p.Wf + (long)pl * p.wf_plane + ((long)(wave * 2 + nt) * KS) * 512 + lane * 8;
-  long woff = 0;
-  int wk = 0, wc = 0;
+  long woff = 16L * KS * 512 * c0;      // a chunk is 16 column blocks x KS steps x 1 KB per plane
+  int wk = 0, wc = c0;
   rg_u32x4 bq[2][2][2];
 #pragma unroll
   for (int i = 0; i < 8; ++i) bq[i >> 2][(i >> 1) & 1][i & 1] = rg_u32x4{0u, 0u, 0u, 0u};
@@ -918,13 +924,13 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wa_kernel(const RowGemmArgs p)
   auto landed_w = [](rg_u32x4& b00, rg_u32x4& b01, rg_u32x4& b10, rg_u32x4& b11) {
     asm volatile("" : "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11)::"memory");
   };
-  auto advance_w = [&]() {      // + 1 KB (512 halves) per step, + 15 KS KB more at a chunk boundary, back to the start after the last chunk
+  auto advance_w = [&]() {      // + 1 KB (512 halves) per step, + 15 KS KB more at a chunk boundary, back to this workgroup's first chunk after its last
     const bool wrap = ++wk == KS;
     if (wrap) {
       wk = 0;
-      const bool end = ++wc == NC;
-      if (end) wc = 0;
-      woff += end ? 512L + 15L * KS * 512 - 16L * KS * 512 * NC : 512L + 15L * KS * 512;
+      const bool end = ++wc == c1;
+      if (end) wc = c0;
+      woff += end ? 512L + 15L * KS * 512 - 16L * KS * 512 * (c1 - c0) : 512L + 15L * KS * 512;
     } else {
       woff += 512L;
     }
@@ -956,7 +962,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wa_kernel(const RowGemmArgs p)
 
   int ks1 = 1;      // (step + 1) % KS: the stage the next step reads
   bool waited = false;
-  for (int c = 0; c < NC; ++c) {
+  for (int c = c0; c < c1; ++c) {
 #pragma unroll
     for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
@@ -1000,7 +1006,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wa_kernel(const RowGemmArgs p)
       step(std::integral_constant<int, 0>{});
       step(std::integral_constant<int, 1>{});
     }
-    if (c + 1 < NC) {      // what the next step's wait needs -- W0(s + 1), W1(s) -- has only W1(s + 1) behind it so far
+    if (c + 1 < c1) {      // what the next step's wait needs -- W0(s + 1), W1(s) -- has only W1(s + 1) behind it so far
       rg_wait_vmcnt<2>();
       waited = true;
     }

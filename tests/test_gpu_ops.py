@@ -42,6 +42,14 @@ def rel_err(got, want):
     return float((got.double().cpu() - want).abs().max() / (want.abs().max() + 1e-12))
 
 
+def row_err(got, want, scale):
+    """worst row of |got - want| against that ROW's own scale (`scale` [rows]: what the row's sum is made of, e.g.
+    (|A| @ |W|^T).max + |res|.max) -- a global maximum in the denominator would let a wrong small-magnitude row hide
+    behind a large one"""
+    e = (got.double().cpu() - want).abs().amax(dim=1)
+    return float((e / scale.clamp_min(1e-30)).max())
+
+
 @pytest.mark.parametrize("M,K,N", [(300, 256, 1536), (19, 1024, 256), (2, 320, 1024), (1000, 512, 80), (129, 256, 18),
                                    (4100, 256, 256)])
 def test_linear(dev, M, K, N):
@@ -500,6 +508,21 @@ def test_rowgemm_epilogues(dev, monkeypatch):
     want = Ad @ W2.double().cpu().T + b2.double().cpu() + res.double().cpu()
     assert rel_err(out, want) < 2e-6
     assert float(slot) == float(out.abs().max())
+    # row by row, with residual rows spread over six decades (a row whose residual is tiny next to one whose residual is
+    # huge): every row within 2e-6 of ITS OWN scale -- the operand bound times the weights' row sums (what the fp16x3 split
+    # guarantees, rowgemm_kernel.h) plus its residual
+    decades = 10.0 ** (torch.arange(M) % 7 - 3).double()
+    res_w = (res.double().cpu() * decades[:, None]).float().to(dev)
+    out_w = op_rowgemm(A, W2, b2, epi="res", res=res_w, a_bound=8.0)
+    want_w = Ad @ W2.double().cpu().T + b2.double().cpu() + res_w.double().cpu()
+    scale = 8.0 * W2.double().cpu().abs().sum(dim=1).max() + res_w.double().cpu().abs().amax(dim=1)
+    assert row_err(out_w, want_w, scale) < 2e-6
+    out_ln, planes_w = op_rowgemm(A, W2, b2, epi="res_ln", res=res_w, ln=(torch.ones(256, device=dev), torch.zeros(256, device=dev)),
+                                  a_bound=8.0, out2_scale=1024.0)
+    assert row_err(out_ln, want_w, scale) < 2e-6
+    # the LayerNorm planes of those rows are unit-scale whatever the row's magnitude: an absolute bound IS per-row relative
+    ln_w = F.layer_norm(want_w, (256,), None, None, 1e-5)
+    assert float((planes_w.double().cpu() - ln_w).abs().max()) < 1e-5
     # in place (res aliases out, as the estimator runs it) + LayerNorm of the new row -> planes
     lg = (1 + 0.1 * torch.randn(256, generator=g)).to(dev)
     lb = (0.02 * torch.randn(256, generator=g)).to(dev)

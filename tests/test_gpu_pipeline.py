@@ -341,3 +341,54 @@ def test_fused_block_equals_separate_launches(monkeypatch):
     for f, s in zip(fused, split):
         assert torch.isfinite(f).all()
         assert torch.equal(f, s), float((f - s).abs().max())
+
+
+def test_split_qkv_equals_fused_block(monkeypatch):
+    """Mid-size batches (64 - 170 row tiles on 256 CUs): the next block's q | k | v leaves the fused launch -- phase B's
+    epilogue writes the LayerNorm1 planes to HBM and rowgemm_wa_kernel runs with its six column chunks dealt over 3 or 6
+    workgroups per row tile (flow.hip `qkv_split`, RowGemmArgs::nsplit).  Same K order and epilogue expressions as the fused
+    launch (JV_NO_QKV_SPLIT=1): the mels must be equal bit for bit, at 3 workgroups per row tile (ragged 8), at 6 (ragged 4) and
+    with a last row tile that is partly past the end"""
+    import jyutvoice_amd
+    from jyutvoice_amd import synth
+    sd = synth.tts_state_dict(fixed_duration=1.5)
+    keys = ("x", "x_lengths", "lang", "tone", "word_pos", "syllable_pos", "spk_embed")
+    cases = [synth.batch(8, 150, first_index=40, lengths=[150 - 11 * i for i in range(8)]),
+             synth.batch(4, 150, first_index=3, lengths=[150, 97, 141, 150]),
+             synth.batch(6, 131, first_index=11, lengths=[131 - 7 * i for i in range(6)])]
+
+    def run():
+        tts, _ = jyutvoice_amd.build_default("cuda:0")
+        tts.load_state_dict(sd)
+        return [tts.synthesise(*[b[k] for k in keys], None, n_timesteps=2, batched=True)["mel"].cpu() for b in cases]
+
+    split = run()
+    monkeypatch.setenv("JV_NO_QKV_SPLIT", "1")
+    fused = run()
+    for f, s in zip(fused, split):
+        assert torch.isfinite(s).all()
+        assert torch.equal(f, s), float((f - s).abs().max())
+
+
+def test_ln_fold_matches_separate_norm(monkeypatch):
+    """A stage's first norm1 runs in the epilogue of the resnet's last convolution (RowConvArgs::ln2_out, rowconv_wd_kernel)
+    instead of as a launch of its own (JV_NO_LN_FOLD=1: layernorm256_planes).  The two sum a row's 256 channels in different
+    association orders, so the planes may differ in the last bit: the mels agree to 2e-5 (the cross-regime bound), at a
+    tile height of 5 (32 utterances) and 2 (ragged 8, where q | k | v also runs column-split)"""
+    import jyutvoice_amd
+    from jyutvoice_amd import synth
+    sd = synth.tts_state_dict(fixed_duration=1.5)
+    keys = ("x", "x_lengths", "lang", "tone", "word_pos", "syllable_pos", "spk_embed")
+    cases = [synth.batch(32, 150), synth.batch(8, 150, first_index=40, lengths=[150 - 11 * i for i in range(8)])]
+
+    def run():
+        tts, _ = jyutvoice_amd.build_default("cuda:0")
+        tts.load_state_dict(sd)
+        return [tts.synthesise(*[b[k] for k in keys], None, n_timesteps=2, batched=True)["mel"].cpu() for b in cases]
+
+    folded = run()
+    monkeypatch.setenv("JV_NO_LN_FOLD", "1")
+    separate = run()
+    for f, s in zip(folded, separate):
+        assert torch.isfinite(f).all()
+        assert float((f - s).abs().max()) <= 2e-5
