@@ -397,11 +397,18 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   // fused launch: phase B's epilogue writes the LayerNorm1 planes to HBM and rowgemm_wa runs with its chunks dealt over
   // qkv_split workgroups per row tile.  Same K order, same epilogue expressions: the same bits as the fused launch
   // (tests/test_gpu_pipeline.py::test_split_qkv_equals_fused_block).  JV_NO_QKV_SPLIT=1: fused at every batch size.
-  int qkv_split = 1;
+  // The stand-alone launch takes the TALLEST tile: what a launch moves from L2 to the CUs is (row tiles) x (weight bytes) --
+  // at 152 tiles of 32 rows, 228 MB, 21 us at the ~11 TB/s the L2s deliver together, however the chunks are dealt -- so
+  // 80-row tiles (61 of them at 8 utterances) with as many column groups as fit one round of the chip.
+  int qkv_split = 1, qkv_rt = 0;
   if (use_rg && !c.no_qkv_split) {
     const int rt = rowgemm_tile((int)g.M);
     const long wgs = rt > 0 ? cdivl(g.M, 16 * rt) : 0;
-    if (wgs > 0 && wgs <= 170) qkv_split = wgs <= 85 ? 6 : 3;
+    if (wgs > 0 && wgs <= 192) {
+      qkv_rt = 5;
+      const long tiles = cdivl(g.M, 80);
+      qkv_split = tiles * 6 <= 256 ? 6 : tiles * 3 <= 256 ? 3 : 2;
+    }
   }
   // `qkv_ready`: the previous block's fused launch has already produced this block's q | k | v (rowblock_kernel.h);
   // `qkv_next` (out): this block's launch produced the next block's
@@ -424,7 +431,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     at.out2 = reinterpret_cast<unsigned short*>(w.att); at.out2_plane = R * 512; at.out2_scale = b.out.a_scale;
     if (!c.no_attn_planes) {
       if (!qkv_ready) {
-        a.nsplit = qkv_split;
+        a.nsplit = qkv_split; a.rt = qkv_rt;
         a.out = w.qkv; a.ldo = 512;
         a.out2 = kv2; a.out2_plane = R * 1024; a.ldo2 = 1024; a.out2_scale = b.k_scale; a.out2_scale2 = b.v_scale;
         JV_TRY(rowgemm(a, RG_QKV, st));

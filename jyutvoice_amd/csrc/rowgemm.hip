@@ -247,7 +247,7 @@ int rowgemm(const RowGemmArgs& a, int epi, hipStream_t st) {
     return fail(JV_ERR_ARG, "rowgemm: the qkv epilogue wants N = 1536, a q buffer and a K/V plane buffer");
   if ((epi == RG_GELU_PL || epi == RG_RES_LN) && (!a.out2 || (a.ldo2 & 3))) return fail(JV_ERR_ARG, "rowgemm: bad plane output");
   if (epi == RG_RES_LN && (!a.ln_g || !a.ln_b)) return fail(JV_ERR_ARG, "rowgemm: LayerNorm epilogue needs gain and offset");
-  int rt = rowgemm_tile(a.M);
+  int rt = (a.rt >= 2 && a.rt <= 5) ? a.rt : rowgemm_tile(a.M);
   if (rt == 0) rt = 2;      // callers ask rowgemm_tile() first; a direct call still works
   switch (rt) {
     case 1:

@@ -75,6 +75,8 @@ struct RowGemmArgs {
   const unsigned char* row_mask;
   long alg_rows;      // profiler: real frames
   int nsplit;         // rowgemm_wa_kernel: the N / 256 column chunks are dealt to nsplit workgroups per row tile (grid.y); 0 / 1: one
+  int rt;             // tile height in 16-row units, 2 .. 5; 0: rowgemm_tile(M).  A stand-alone launch need not take the fused block's:
+                      // the L2 -> CU traffic of a launch is (row tiles) x (weight bytes), so few tall tiles x column split moves the least
   int ablate;         // tuning aid (JV_RG_ABLATE, tuning builds): 1 no loads in the loop, 2 no MFMAs, 4 no barrier/wait (LDS kernel),
                       // W-direct kernel also: 8 no LDS fragment reads, 16 no W loads, 32 no A DMA, 64 no row pass
 };
