@@ -50,6 +50,9 @@ struct FlowWs {
   float *d = nullptr;                                                 // [rows,80]
   float *tsin = nullptr, *t1 = nullptr, *tmish = nullptr, *temb = nullptr;
   float *t_dev = nullptr, *t_table = nullptr, *dt_table = nullptr;
+  // cfm_solve: the timestep embedding of EVERY step of a solve, computed in three launches before the loop (the steps'
+  // t are known up front and the same for all rows): [TS_MAX] rows of sinusoid / hidden / Mish / the 14 projections
+  float *ts_sin = nullptr, *ts_1 = nullptr, *ts_mish = nullptr, *ts_emb = nullptr;
   unsigned char* rowmask = nullptr;
   int* row_sample = nullptr;
   int* lens2 = nullptr;     // [2*maxB]
@@ -60,11 +63,13 @@ struct FlowWs {
   // default stream, which cannot be captured), fenced against the caller's stream with events.
   int* step_ctr = nullptr;
   float *t_cur = nullptr, *dt_cur = nullptr;
-  struct StepGraph { int B, T, chunk; hipGraph_t graph; hipGraphExec_t exec; };
+  struct StepGraph { int B, T, chunk, pre; hipGraph_t graph; hipGraphExec_t exec; };      // pre: captured with the embeddings precomputed
   std::vector<StepGraph> graphs;
   hipStream_t gstream = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
 };
+
+constexpr int TS_MAX = 64;      // steps whose timestep embeddings cfm_solve computes ahead of the loop (more: per step, as the seam does)
 
 static long flow_rows(int B2, int T) { return (long)FLOW_G + (long)B2 * (T + FLOW_GAP); }
 
@@ -99,6 +104,10 @@ int flow_ws_create(Context& c) {
   w->amax_stride = B2;
   JV_TRY(F(&w->amax, (size_t)3 * B2));
   JV_TRY(F(&w->t_dev, (size_t)B2));
+  JV_TRY(F(&w->ts_sin, (size_t)TS_MAX * 320));
+  JV_TRY(F(&w->ts_1, (size_t)TS_MAX * 1024));
+  JV_TRY(F(&w->ts_mish, (size_t)TS_MAX * 1024));
+  JV_TRY(F(&w->ts_emb, (size_t)TS_MAX * EST_NRES * 256));
   JV_TRY(F(&w->t_table, (size_t)w->max_steps));
   JV_TRY(F(&w->dt_table, (size_t)w->max_steps));
   JV_TRY(ws_alloc(c, R, reinterpret_cast<void**>(&w->rowmask)));
@@ -132,12 +141,19 @@ void flow_ws_forget_attention(Context& c, hipStream_t st) {
 namespace {
 
 // (t, dt) of the step the device-side counter points at, then advance it: the only step-dependent state of a solve
+// (256 threads; emb_steps != null: the step's precomputed timestep embedding, [EST_NRES * 256] floats, moves to the fixed
+// place the estimator's launches read it from -- their arguments are frozen inside a captured graph)
 __global__ void step_advance_kernel(const float* __restrict__ t_table, const float* __restrict__ dt_table, int* ctr,
-                                    float* t_cur, float* dt_cur) {
+                                    float* t_cur, float* dt_cur, const float* __restrict__ emb_steps, float* __restrict__ emb_cur) {
   const int i = *ctr;
-  *t_cur = t_table[i];
-  *dt_cur = dt_table[i];
-  *ctr = i + 1;
+  if (emb_steps)
+    for (int k = threadIdx.x; k < EST_NRES * 256; k += 256) emb_cur[k] = emb_steps[(long)i * EST_NRES * 256 + k];
+  __syncthreads();      // every thread has read the counter
+  if (threadIdx.x == 0) {
+    *t_cur = t_table[i];
+    *dt_cur = dt_table[i];
+    *ctr = i + 1;
+  }
 }
 
 struct Geo {
@@ -146,6 +162,7 @@ struct Geo {
   long a_rows;   // rows that may be read
   const float* t_ptr = nullptr;   // timestep per utterance: t_ptr[b * t_stride]
   int t_stride = 1;
+  bool temb_pre = false;          // w.temb row 0 already holds this step's embedding, the same for every utterance (cfm_solve)
 };
 
 ConvGemmArgs base_args(const Geo& g, const float* A, int lda, const GemmW& w, float* out, int ldo) {
@@ -160,6 +177,22 @@ ConvGemmArgs base_args(const Geo& g, const float* A, int lda, const GemmW& w, fl
   return a;
 }
 
+// timestep embedding of n timesteps t[i * t_stride]: sinusoid -> Linear + SiLU -> Linear (+ Mish, the only consumer) -> the 14
+// resnets' projections, emb [n, 14 * 256] (decoder.py:917-935, 98-108).  Rows are independent: a row's bits do not depend on n.
+int time_embedding(Context& c, const float* t, int t_stride, int n, float* sin_buf, float* h1, float* hm, float* emb, hipStream_t st) {
+  const EstimatorW& e = c.est;
+  JV_TRY(time_sinusoid(t, t_stride, sin_buf, n, st));
+  Geo tg{n, 1, 1, n, n, nullptr, 1};
+  ConvGemmArgs a = base_args(tg, sin_buf, 320, e.time1, h1, 1024);
+  a.act = ACT_SILU;
+  JV_TRY(conv_gemm(a, 1, st));
+  a = base_args(tg, h1, 1024, e.time2, hm, 1024);
+  a.act = ACT_MISH;
+  JV_TRY(conv_gemm(a, 1, st));
+  a = base_args(tg, hm, 1024, e.temb_all, emb, EST_NRES * 256);
+  return conv_gemm(a, 1, st);
+}
+
 // the estimator body on prepared inputs: ws.xin [rows,320], ws.rowmask/row_sample/lens2, ws.t_dev [B2] -> ws.d [rows,80]
 int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   FlowWs& w = *c.flow;
@@ -167,18 +200,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   const int B2 = g.B2;
 
   // ---- timestep embedding: sinusoid -> Linear+SiLU -> Linear (+Mish, the only consumer) -> 14 projections
-  JV_TRY(time_sinusoid(g.t_ptr, g.t_stride, w.tsin, B2, st));
-  {
-    Geo tg{B2, 1, 1, B2, B2, nullptr, 1};
-    ConvGemmArgs a = base_args(tg, w.tsin, 320, e.time1, w.t1, 1024);
-    a.act = ACT_SILU;
-    JV_TRY(conv_gemm(a, 1, st));
-    a = base_args(tg, w.t1, 1024, e.time2, w.tmish, 1024);
-    a.act = ACT_MISH;
-    JV_TRY(conv_gemm(a, 1, st));
-    a = base_args(tg, w.tmish, 1024, e.temb_all, w.temb, EST_NRES * 256);
-    JV_TRY(conv_gemm(a, 1, st));
-  }
+  if (!g.temb_pre) JV_TRY(time_embedding(c, g.t_ptr, g.t_stride, B2, w.tsin, w.t1, w.tmish, w.temb, st));
 
   auto causal3 = [&](ConvGemmArgs& a) {   // CausalConv1d k=3: rows t-2, t-1, t of the masked input
     a.tap_row0 = -2;
@@ -238,12 +260,26 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   // A causal k = 3 convolution of a trunk buffer: on the row-owning kernel (rowconv_kernel.h: LayerNorm / Mish / mask / time
   // embedding / residual in its epilogue, no ln_epilogue_rows pass) when the batch fills the chip, else on the tile kernels
   const bool use_rc = !c.exact_range && !c.no_rowgemm && rowgemm_tile((int)g.M) > 0;
+  // one decision for every block of the call (a block's split-K tail writes the NEXT block's LayerNorm): all of them take
+  // the split-plane route, or none is split
+  bool sk_blocks = ksplit > 1 && !c.dma_a && !dyn_env("JV_NO_X6");
+  for (int i = 0; i < EST_NRES && sk_blocks; ++i)
+    for (int j = 0; j < EST_NBLK; ++j) {
+      const GemmW &o = e.blk[i][j].out, &f = e.blk[i][j].ff2;
+      sk_blocks = sk_blocks && (o.w3 || o.w2) && (f.w3 || f.w2) && !(o.ldw & 7) && !(f.ldw & 7);
+    }
   // `follow` / `followed`: the transformer block whose norm1 reads this convolution's output (a resnet's second
   // convolution, in place in the trunk): on the W-direct row-owning kernel its LayerNorm planes are written by the
   // convolution's own epilogue (RowConvArgs::ln2_out) and *followed is set; every other route leaves it to the caller
   auto conv3 = [&](ConvGemmArgs& a, const GemmW& m, const BtbW* follow = nullptr, bool* followed = nullptr) -> int {
     if (followed) *followed = false;
-    if (splittable(a) && a.N == 256 && !a.res2) return splitk(a, nullptr, nullptr);
+    if (splittable(a) && a.N == 256 && !a.res2) {
+      // split-K tiles: the reduce kernel's tail writes the following norm1 too (fp32 rows into w.ln, what the split-K
+      // blocks read), as it does between the blocks of a stage
+      const bool fl = follow && followed && sk_blocks && !c.no_ln_fold && a.out == w.h && a.ldo == 256;
+      if (fl) *followed = true;
+      return splitk(a, fl ? &follow->n1 : nullptr, fl ? w.ln : nullptr);
+    }
     if (!use_rc || !a.amax_in || !m.w2 || a.ntaps != 3 || a.tap_row0 != -2 || a.N != 256 || a.ldo != 256 && a.ldo != 512)
       return conv_gemm(a, 1, st);
     RowConvArgs r{};
@@ -285,7 +321,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     causal3(a);
     a.ln = 1; a.ln_g = r.ln1.g; a.ln_b = r.ln1.b; a.ln_eps = 1e-5f; a.act = ACT_MISH;
     a.rowmask_out = w.rowmask;
-    a.rowvec = w.temb + i * 256; a.row_sample = w.row_sample; a.rowvec_ld = EST_NRES * 256;
+    a.rowvec = w.temb + i * 256; a.row_sample = w.row_sample; a.rowvec_ld = g.temb_pre ? 0 : EST_NRES * 256;      // (0: one embedding for all rows)
     h3m(a, r.block1);
     track(a);      // -> h2
     JV_TRY(conv3(a, r.block1));
@@ -318,14 +354,6 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     if (pre(m)) return layernorm256_planes(h, reinterpret_cast<unsigned short*>(w.ln), R * 256, m.a_scale, n.g, n.b, 1e-5f, g.M, st);
     return layernorm_rows(h, nullptr, w.ln, n.g, n.b, 1e-5f, g.M, 256, nullptr, st);
   };
-  // one decision for every block of the call (a block's split-K tail writes the NEXT block's LayerNorm): all of them take
-  // the split-plane route, or none is split
-  bool sk_blocks = ksplit > 1 && !c.dma_a && !dyn_env("JV_NO_X6");
-  for (int i = 0; i < EST_NRES && sk_blocks; ++i)
-    for (int j = 0; j < EST_NBLK; ++j) {
-      const GemmW &o = e.blk[i][j].out, &f = e.blk[i][j].ff2;
-      sk_blocks = sk_blocks && (o.w3 || o.w2) && (f.w3 || f.w2) && !(o.ldw & 7) && !(f.ldw & 7);
-    }
   auto btb = [&](const BtbW& b, const BtbW* next, bool ln_ready, float* h, float* out, int ldo) -> int {
     const bool sk = sk_blocks;      // split-K tails also write the next LayerNorm (fp32 rows) into w.ln
     if (!(sk && ln_ready)) JV_TRY(ln_to(b.n1, b.qkv, h));
@@ -542,7 +570,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     for (int j = 0; j < EST_NBLK; ++j) {
       const bool last = j == EST_NBLK - 1;
       if (all) JV_TRY(btb_rg(blk[j], last ? nullptr : &blk[j + 1], j > 0 || ln_first, qkv_ready, &qkv_ready, h, last ? last_out : h, last ? last_ldo : 256));
-      else JV_TRY(btb(blk[j], last ? nullptr : &blk[j + 1], j > 0, h, last ? last_out : h, last ? last_ldo : 256));
+      else JV_TRY(btb(blk[j], last ? nullptr : &blk[j + 1], j > 0 || ln_first, h, last ? last_out : h, last ? last_ldo : 256));
     }
     return JV_OK;
   };
@@ -550,7 +578,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   // down: resnet -> 4 blocks (result doubles as the skip) -> causal conv
   // (a stage on the row-owning kernels takes its first norm1 from the resnet's last convolution)
   bool lnf = false;
-  auto follow_of = [&](const BtbW* blk) -> const BtbW* { return stage_all_rg(blk) ? blk : nullptr; };
+  auto follow_of = [&](const BtbW* blk) -> const BtbW* { return (stage_all_rg(blk) || sk_blocks) ? blk : nullptr; };
   JV_TRY(resnet(0, w.xin, 320, w.h, 256, follow_of(e.blk[0]), &lnf));
   JV_TRY(stage_blocks(e.blk[0], w.h, skip, 512, lnf));
   {
@@ -688,8 +716,14 @@ int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spk
   JV_HIP(hipMemsetAsync(w.amax, 0, sizeof(float) * 3 * w.amax_stride, st));      // trunk bounds: maxima over the whole solve
   JV_HIP(hipMemcpyAsync(w.spks, spks, sizeof(float) * 80 * B, hipMemcpyDeviceToDevice, st));
   g.t_ptr = w.t_cur;   // the same t for all 2B rows (stride 0)
+  // Every step's t is on the device already and is the same for all rows: the n embeddings are three GEMMs of n rows HERE
+  // instead of three GEMMs of 2B identical rows inside every step -- K = 1024 contractions of one row tile, 20 - 48 us each
+  // at any batch size, 1.2 ms of serial launches per solve (JV_NO_TEMB_PRE=1: per step, as jv_flow_estimator_masked does)
+  g.temb_pre = !c.no_temb_pre && n_timesteps <= TS_MAX;
+  if (g.temb_pre) JV_TRY(time_embedding(c, w.t_table, 1, n_timesteps, w.ts_sin, w.ts_1, w.ts_mish, w.ts_emb, st));
   auto euler_step = [&](hipStream_t s) -> int {
-    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, w.t_table, w.dt_table, w.step_ctr, w.t_cur, w.dt_cur);
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(256), 0, s, w.t_table, w.dt_table, w.step_ctr, w.t_cur, w.dt_cur,
+                       g.temb_pre ? w.ts_emb : nullptr, w.temb);
     JV_TRY(assemble_xin(w.x, w.mu, w.spks, w.cond, w.xin, B, FLOW_G, g.S, T, g.M, s));
     JV_TRY(estimator_body(c, g, s));
     return euler_cfg(w.x, w.d, B, FLOW_G, g.S, T, w.dt_cur, 0, 0.7f, s);
@@ -701,7 +735,7 @@ int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spk
   } else {
     FlowWs::StepGraph* sg = nullptr;
     for (auto& e : w.graphs)
-      if (e.B == B && e.T == T && e.chunk == c.attn_chunk) sg = &e;
+      if (e.B == B && e.T == T && e.chunk == c.attn_chunk && e.pre == (int)g.temb_pre) sg = &e;
     int first = 0;
     if (!sg) {
       // first solve of this geometry: step 0 runs eagerly (it also performs the one-time kernel attribute setup),
@@ -729,7 +763,7 @@ int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spk
         (void)hipGraphDestroy(w.graphs.front().graph);
         w.graphs.erase(w.graphs.begin());
       }
-      w.graphs.push_back({B, T, c.attn_chunk, graph, exec});
+      w.graphs.push_back({B, T, c.attn_chunk, (int)g.temb_pre, graph, exec});
       sg = &w.graphs.back();
     } else {
       JV_HIP(hipEventRecord(w.ev_in, st));

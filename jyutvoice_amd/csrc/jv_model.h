@@ -132,6 +132,7 @@ struct Context {
   bool dma_a = false;            // JV_DMA_A=1: fp16x3 linears take their A operand pre-split from the producer (measured slower
                                  // in the pipeline than the in-kernel split; kept as a tested alternative)
   bool no_ffn_fuse = false;      // JV_NO_FFN_FUSE=1: ff.net.0 and ff.net.2 as two launches (the path rowffn_kernel is checked against)
+  bool no_temb_pre = false;      // JV_NO_TEMB_PRE=1: the timestep embedding inside every Euler step instead of once per solve (flow.hip cfm_solve)
   bool no_ln_fold = false;       // JV_NO_LN_FOLD=1: a stage's first norm1 as its own launch (layernorm256_planes) instead of in the resnet's last convolution
   bool no_qkv_split = false;     // JV_NO_QKV_SPLIT=1: q|k|v stays inside the fused block launch at every batch size (flow.hip `qkv_split`)
   bool no_block_fuse = false;    // JV_NO_BLOCK_FUSE=1: to_out / feed-forward / next q|k|v as three launches (the path rowblock_kernel is checked against)

@@ -374,12 +374,14 @@ def test_ln_fold_matches_separate_norm(monkeypatch):
     """A stage's first norm1 runs in the epilogue of the resnet's last convolution (RowConvArgs::ln2_out, rowconv_wd_kernel)
     instead of as a launch of its own (JV_NO_LN_FOLD=1: layernorm256_planes).  The two sum a row's 256 channels in different
     association orders, so the planes may differ in the last bit: the mels agree to 2e-5 (the cross-regime bound), at a
-    tile height of 5 (32 utterances) and 2 (ragged 8, where q | k | v also runs column-split)"""
+    tile height of 5 (32 utterances) and 2 (ragged 8, where q | k | v also runs column-split), and on the split-K tiles of a
+    single utterance (the norm leaves the reduce kernel's tail, rowops.hip splitk_reduce_kernel)"""
     import jyutvoice_amd
     from jyutvoice_amd import synth
     sd = synth.tts_state_dict(fixed_duration=1.5)
     keys = ("x", "x_lengths", "lang", "tone", "word_pos", "syllable_pos", "spk_embed")
-    cases = [synth.batch(32, 150), synth.batch(8, 150, first_index=40, lengths=[150 - 11 * i for i in range(8)])]
+    cases = [synth.batch(32, 150), synth.batch(8, 150, first_index=40, lengths=[150 - 11 * i for i in range(8)]),
+             synth.batch(1, 64, first_index=9)]      # (one utterance: the split-K tiles, whose reduce tail writes the norm)
 
     def run():
         tts, _ = jyutvoice_amd.build_default("cuda:0")
@@ -392,3 +394,28 @@ def test_ln_fold_matches_separate_norm(monkeypatch):
     for f, s in zip(folded, separate):
         assert torch.isfinite(f).all()
         assert float((f - s).abs().max()) <= 2e-5
+
+
+def test_timestep_embeddings_once_per_solve(monkeypatch):
+    """cfm_solve computes the timestep embedding of every Euler step ahead of the loop (three GEMMs of n_timesteps rows) and
+    each step copies its row into place; JV_NO_TEMB_PRE=1 computes it inside every step for all 2B (identical) rows, as the
+    TRT-seam entry point does for a caller's own t.  GEMM rows are independent of the row count: the mels must be equal bit
+    for bit -- one utterance (split-K tiles), a ragged 8 (row-owning kernels), and n_timesteps = 1 and 7"""
+    import jyutvoice_amd
+    from jyutvoice_amd import synth
+    sd = synth.tts_state_dict(fixed_duration=1.5)
+    keys = ("x", "x_lengths", "lang", "tone", "word_pos", "syllable_pos", "spk_embed")
+    cases = [(synth.batch(1, 64), 7), (synth.batch(8, 150, first_index=40, lengths=[150 - 11 * i for i in range(8)]), 2),
+             (synth.batch(2, 33, first_index=5), 1)]
+
+    def run():
+        tts, _ = jyutvoice_amd.build_default("cuda:0")
+        tts.load_state_dict(sd)
+        return [tts.synthesise(*[b[k] for k in keys], None, n_timesteps=n, batched=True)["mel"].cpu() for b, n in cases]
+
+    pre = run()
+    monkeypatch.setenv("JV_NO_TEMB_PRE", "1")
+    per_step = run()
+    for a, b in zip(pre, per_step):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), float((a - b).abs().max())
