@@ -364,7 +364,7 @@ int x6_launch4(const ConvGemmArgs& a_in, hipStream_t st) {
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, st);
-    hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, NWB, NP>), dim3(nwg), dim3(256), lds, st, b, tiles_n);
+    hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WM, WN, PRO, EPI, NA2, NWB, NP>), dim3(nwg, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, st, b, tiles_n);      // (the splits of a tile share its stamp slot: the last writer's)
     (void)hipEventRecord(e1, st);
     (void)hipStreamSynchronize(st);
     float ms = 0.f;
@@ -382,8 +382,8 @@ int x6_launch4(const ConvGemmArgs& a_in, hipStream_t st) {
         if (h[4 * i + 3] > t1) t1 = h[4 * i + 3];
       }
       const double span = (double)(t1 - t0);
-      fprintf(stderr, "[stamps x6] %dx%d grid %u: prologue %.0f  loop %.0f  epilogue %.0f ticks avg per workgroup; span %.0f ticks, %.1f us by events (%.1f ticks/us); mean resident workgroups %.1f\n",
-              BM, BN, nwg, pro / nwg, loop / nwg, epi / nwg, span, ms * 1e3, span / (ms * 1e3), (pro + loop + epi) / span);
+      fprintf(stderr, "[stamps x6] %dx%d K %d taps %d split %d N %d grid %u: prologue %.0f  loop %.0f  epilogue %.0f ticks avg per workgroup; span %.0f ticks, %.1f us by events (%.1f ticks/us); mean resident workgroups %.1f\n",
+              BM, BN, a.Cin, a.ntaps, a.ksplit, a.N, nwg, pro / nwg, loop / nwg, epi / nwg, span, ms * 1e3, span / (ms * 1e3), (pro + loop + epi) / span);
     }
     return JV_OK;
   }
