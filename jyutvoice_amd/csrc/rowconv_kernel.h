@@ -615,6 +615,13 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
   stamp();      // 3: main loop done
   if (JV_ABLATE(p, 16)) return;
   const bool mish = p.act == ACT_MISH;      // (uniform) the one activation the estimator uses here
+  // gain / offset of the following norm (ln2_out): requested here, in front of the slab writes and their barrier -- inside the row
+  // pass each row group began by sitting out their L2 round trip
+  rg_f32x4 g2 = {1.f, 1.f, 1.f, 1.f}, b2 = {0.f, 0.f, 0.f, 0.f};
+  if (p.ln2_out) {
+    g2 = *reinterpret_cast<const rg_f32x4*>(p.ln2_g + 4 * lane);
+    b2 = *reinterpret_cast<const rg_f32x4*>(p.ln2_b + 4 * lane);
+  }
   float* const slab = reinterpret_cast<float*>(rc_lds + SLAB_OFF);      // its own region: nothing to wait for before writing it
 #pragma unroll
   for (int mt = 0; mt < RT; ++mt)
@@ -697,8 +704,6 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
 #pragma unroll
       for (int jj = 1; jj < RPW; ++jj) var_l = lane == jj ? sq[jj] : var_l;
       const float rstd_l = 1.0f / sqrtf(var_l * (1.f / 256.f) + p.ln_eps);
-      const rg_f32x4 g2 = *reinterpret_cast<const rg_f32x4*>(p.ln2_g + 4 * lane);
-      const rg_f32x4 b2 = *reinterpret_cast<const rg_f32x4*>(p.ln2_b + 4 * lane);
 #pragma unroll
       for (int jj = 0; jj < RPW; ++jj) {
         const long mrow = (long)m0 + wave * 2 * RT + ps * RT + jj;
