@@ -206,12 +206,14 @@ def main():
     torch.cuda.set_device(dev_index)                             # when rehearsing several ranks on a 1-GPU box (gloo)
     device = torch.device("cuda", dev_index)
     use_dist = world > 1 or os.environ.get("JV_FORCE_DIST") == "1"   # JV_FORCE_DIST: run the collective path with one rank
+    coll_dev = device      # where the collectives' tensors live: the GPU under RCCL, the host under gloo (rehearsals on one card)
     if use_dist:
         backend = os.environ.get("JV_DIST_BACKEND", "nccl")      # nccl == RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+            coll_dev = "cpu"
 
     import jyutvoice_amd
     from jyutvoice_amd import dist as jdist
@@ -240,15 +242,20 @@ def main():
 
     src = {}
 
-    def step():
+    def step(gather=True):
+        """one pass; gather=False leaves out the end-of-step collective (passes that only SOME ranks run, outside the timed
+        region: a collective entered by rank 0 alone would wait for the others forever)"""
         if args.workload == "c2":
             mel = eng.cfm_solve(c2_mu, None, c2_spks, c2_cond, n_steps, 1.0)
             return {"mel": mel, "mel_lengths": None}, None
         res = tts.synthesise(batch["x"], batch["x_lengths"], batch["lang"], batch["tone"], batch["word_pos"],
                              batch["syllable_pos"], batch["spk_embed"], None, n_timesteps=n_steps, batched=True)
         wav, src["s"] = hift.inference(res["mel"])
-        if use_dist:
-            jdist.all_gather_mels(res["mel"], res["mel_lengths"])
+        if use_dist and gather:
+            if coll_dev == "cpu":      # gloo rehearsal: host tensors
+                jdist.all_gather_mels(res["mel"].cpu(), res["mel_lengths"].cpu())
+            else:
+                jdist.all_gather_mels(res["mel"], res["mel_lengths"])
         return res, wav
 
     def timed_loop(n, profiled_steps=0):
@@ -267,7 +274,7 @@ def main():
             dist.barrier()
         el = time.perf_counter() - t0
         if use_dist:
-            t = torch.tensor([el], dtype=torch.float64, device=device)
+            t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, out
@@ -320,7 +327,7 @@ def main():
         runs = []
         for _ in range(3):
             tts.stage_events = []
-            step_res, _ = step()
+            step_res, _ = step(gather=False)      # rank 0 alone runs these
             e_end = torch.cuda.Event(enable_timing=True)
             e_end.record(torch.cuda.current_stream(device))
             torch.cuda.synchronize(device)

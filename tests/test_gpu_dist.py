@@ -73,3 +73,42 @@ def test_two_rank_shards_equal_single_process(tmp_path, tts_sd, tokens, same_ker
         assert torch.equal(got["mel"], want), float((got["mel"] - want).abs().max())
     else:
         assert float((got["mel"] - want).abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("strong", [False, True])
+def test_bench_script_runs_with_two_ranks(strong):
+    """bench.py itself as the driver starts it for N = 2 -- one process per rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    the environment -- rehearsed on the one card with gloo (JV_DIST_BACKEND=gloo; the modulo in bench.py puts both ranks on
+    GPU 0): every rank must reach the end (a collective entered by rank 0 alone, as the per-stage passes once did, hangs here
+    until the timeout), rank 0 prints ONE JSON line for the whole job, the others print none"""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
+    import json
+    port = _free_port()
+    flags = ["--gpus", "2", "--tokens", "20", "--timesteps", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-exact-range"]
+    flags += ["--strong", "--total-batch", "6"] if strong else ["--batch", "3"]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   JV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "bench.py"), *flags], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, e = p.communicate()
+        outs.append((p.returncode, o.decode(errors="replace"), e.decode(errors="replace")[-1500:]))
+    assert all(rc == 0 for rc, _, _ in outs), outs
+    lines0 = [ln for ln in outs[0][1].splitlines() if ln.startswith("{")]
+    lines1 = [ln for ln in outs[1][1].splitlines() if ln.startswith("{")]
+    assert len(lines0) == 1 and not lines1, (lines0, lines1)
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 2 and d["scaling"] == ("strong" if strong else "weak")
+    assert d["config"]["global_batch"] == 6
+    assert d["stage_ms"]["cfm_loop"] > 0          # rank 0's per-stage passes ran (without the collective)
+    # whole-job frames over the slowest rank's time
+    assert abs(d["value"] - 6 * 40 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-3 * d["value"]
+
