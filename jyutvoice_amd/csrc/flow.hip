@@ -425,9 +425,9 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   // fused launch: phase B's epilogue writes the LayerNorm1 planes to HBM and rowgemm_wa runs with its chunks dealt over
   // qkv_split workgroups per row tile.  Same K order, same epilogue expressions: the same bits as the fused launch
   // (tests/test_gpu_pipeline.py::test_split_qkv_equals_fused_block).  JV_NO_QKV_SPLIT=1: fused at every batch size.
-  // The stand-alone launch takes the TALLEST tile: what a launch moves from L2 to the CUs is (row tiles) x (weight bytes) --
-  // at 152 tiles of 32 rows, 228 MB, 21 us at the ~11 TB/s the L2s deliver together, however the chunks are dealt -- so
-  // 80-row tiles (61 of them at 8 utterances) with as many column groups as fit one round of the chip.
+  // The stand-alone launch takes the TALLEST tile: what a launch requests from L2 is (row tiles) x (weight bytes) -- at 152
+  // tiles of 32 rows 228 MB, and dealing the chunks of those tiles out moved it only from 27 to 21 us -- so 80-row tiles (61
+  // of them at 8 utterances, 92 MB) with as many column groups as fit one round of the chip: 19 us.
   int qkv_split = 1, qkv_rt = 0;
   if (use_rg && !c.no_qkv_split) {
     const int rt = rowgemm_tile((int)g.M);
