@@ -419,7 +419,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   auto rg_track = [&](RowGemmArgs& a) {
     a.amax_out = slots_of(a.out); a.row_slot = w.row_sample; a.row_mask = w.rowmask;
   };
-  // Few row tiles (3 - 10 utterances of 300 frames: 64 - 170 workgroups of 32 rows on 256 CUs): a workgroup's length is set
+  // Few row tiles (3 - 10 utterances of 300 frames: 64 - 192 workgroups of 32 rows on 256 CUs): a workgroup's length is set
   // by the weights it streams through its CU's L2 port, not by its MFMAs, and a third of the fused block's steps are the
   // next block's q | k | v, whose six 256-column chunks need nothing from each other.  There the q | k | v phase leaves the
   // fused launch: phase B's epilogue writes the LayerNorm1 planes to HBM and rowgemm_wa runs with its chunks dealt over
