@@ -12,7 +12,9 @@ mel extractor.  Instead this CLI takes their outputs directly:
 
     --tokens tokens.json     {"x": [...], "lang": [...], "tone": [...], "word_pos": [...], "syllable_pos": [...]}
                              (equal-length int lists = the output contract of jyutvoice/text/__init__.py:20-35 after
-                             `intersperse`), optionally "spk_embed": [192 floats], and for voice cloning
+                             `intersperse`; with "interspersed": false the raw text_to_sequence lists, which get their
+                             blanks here -- jyutvoice_amd/utils/text.py validates either form), optionally
+                             "spk_embed": [192 floats], and for voice cloning
                              "prompt_token": [speech-token ids] + either "prompt_feat": [[80 floats] per frame] or
                              "prompt_wav_24k": "ref_24k.wav" (16-bit mono; its mel is extracted on the GPU as
                              infer.py:386 does) -- what infer.py:386-392 gets from --ref_audio; the prompt encoder
@@ -119,11 +121,12 @@ def main(argv=None):
         tts.load_state_dict(ckpt["state_dict"] if "state_dict" in ckpt else ckpt)
         print(f"Loading HiFT vocoder from {args.hift}...")
         hift.load_state_dict(torch.load(args.hift, map_location="cpu"))
+        from jyutvoice_amd.utils.text import load_tokens_json
         tok = json.load(open(args.tokens))
-        ids = {k: torch.tensor(tok[k], dtype=torch.int64).unsqueeze(0) for k in ("x", "lang", "tone", "word_pos", "syllable_pos")}
-        n = ids["x"].shape[1]
-        if any(v.shape[1] != n for v in ids.values()):
-            raise SystemExit("tokens: the five id lists must have equal length")
+        try:      # the contract of get_text (infer.py:189-206): equal lengths, ids inside the embedding tables, blanks in place
+            ids = load_tokens_json(tok)
+        except ValueError as e:
+            raise SystemExit(str(e))
         spk = torch.tensor(tok["spk_embed"], dtype=torch.float32).view(1, 192) if "spk_embed" in tok else torch.randn(1, 192)
         if "prompt_token" in tok and ("prompt_feat" in tok or "prompt_wav_24k" in tok):   # infer.py:386-392
             from jyutvoice_amd.flow.encoder import load_flow_encoder

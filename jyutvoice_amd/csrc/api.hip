@@ -2,6 +2,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 
 #include "../../include/jyutvoice_hip.h"
@@ -75,6 +76,30 @@ static void workspaces_destroy(Context& c) {
   jv::enc_ws_destroy(c);
   jv::prompt_ws_destroy(c);    // sized on demand by its own calls (prompt.hip); capped by max_frames
 }
+
+// Scratch of the operator hooks (jv_op_*: test and tuning aids, but exported): one growing buffer per (device, hook slot),
+// looked up under a lock, so a buffer allocated on device A is never handed out after hipSetDevice(B) and two threads cannot
+// race the grow.  Calls of ONE hook on ONE device still share the buffer: the caller serialises those (stream order does).
+namespace {
+enum OpSlot { OPS_X6 = 0, OPS_H3, OPS_H3_A, OPS_CONV, OPS_RG, OPS_RG_A, OPS_RC, OPS_HIFT, OPS_ATTN, OPS_COUNT };
+int op_scratch(int slot, size_t need, void** out) {
+  struct Buf { void* p = nullptr; size_t cap = 0; };
+  static std::mutex mu;
+  static Buf bufs[64][OPS_COUNT];
+  int dev = 0;
+  JV_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  Buf& b = bufs[dev & 63][slot];
+  if (need > b.cap) {
+    if (b.p) (void)hipFree(b.p);      // (synchronises the device: nothing still reads the old buffer)
+    b.p = nullptr; b.cap = 0;
+    JV_HIP(hipMalloc(&b.p, need));
+    b.cap = need;
+  }
+  *out = b.p;
+  return JV_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -306,14 +331,9 @@ int jv_op_conv_gemm(const float* A, int64_t a_rows, int M, int Cin, int ntaps, i
   a.rowmask_in = rowmask; a.rowmask_out = rowmask;
   a.res1 = res; a.ldr1 = N;
   if (jv::dyn_env("JV_OP_X6")) {   // exercise the bf16x6 main loop: split W into three bf16 planes on the fly
-    static unsigned short* scratch = nullptr;
-    static size_t cap = 0;
+    unsigned short* scratch = nullptr;
     const size_t n = (size_t)N * ntaps * Cin;
-    if (3 * n > cap) {
-      if (scratch) (void)hipFree(scratch);
-      JV_HIP(hipMalloc(reinterpret_cast<void**>(&scratch), 3 * n * sizeof(unsigned short) + 64));
-      cap = 3 * n;
-    }
+    JV_TRY(op_scratch(OPS_X6, 3 * n * sizeof(unsigned short) + 64, reinterpret_cast<void**>(&scratch)));
     JV_TRY(jv::split3_planes(W, scratch, (long)n, static_cast<hipStream_t>(stream)));
     a.W3 = scratch;
     a.w3_plane = (long)n;
@@ -336,15 +356,10 @@ int jv_op_linear_h3(const float* A, int64_t rows, int M, int K, const float* W, 
   if (K % 32 || N <= 0 || M <= 0) return jv::fail(JV_ERR_ARG, "jv_op_linear_h3: K must be a multiple of 32");
   const float sc = jv::h3_scale_for_bound(a_bound);
   if (!(sc > 0.f)) return jv::fail(JV_ERR_ARG, "jv_op_linear_h3: unusable bound");
-  static void* scratch = nullptr;
-  static size_t cap = 0;
+  void* scratch = nullptr;
   const size_t n = (size_t)N * K;
   const size_t need = n * 8 + (size_t)N * 12 + 512;
-  if (need > cap) {
-    if (scratch) (void)hipFree(scratch);
-    JV_HIP(hipMalloc(&scratch, need));
-    cap = need;
-  }
+  JV_TRY(op_scratch(OPS_H3, need, &scratch));
   unsigned short* planes = static_cast<unsigned short*>(scratch);
   float* cs = reinterpret_cast<float*>(static_cast<char*>(scratch) + ((n * 4 + 63) & ~(size_t)63));
   JV_TRY(jv::split2h_planes(W, N, K, cs + N, planes, cs, st));
@@ -355,14 +370,9 @@ int jv_op_linear_h3(const float* A, int64_t rows, int M, int K, const float* W, 
   a.res1 = res; a.ldr1 = N;
   a.W2 = planes; a.w2_plane = (long)n; a.colscale = cs; a.a_scale = sc;
   if (presplit) {      // A as fp16 planes written by a producer kernel; 2 = reuse the planes of the previous call (timing)
-    static unsigned short* ap = nullptr;
-    static size_t acap = 0;
+    unsigned short* ap = nullptr;
     const size_t an = (size_t)rows * K;
-    if (an * 4 > acap) {
-      if (ap) (void)hipFree(ap);
-      JV_HIP(hipMalloc(reinterpret_cast<void**>(&ap), an * 4));
-      acap = an * 4;
-    }
+    JV_TRY(op_scratch(OPS_H3_A, an * 4, reinterpret_cast<void**>(&ap)));
     if (presplit == 1) JV_TRY(jv::split2h_rows(A, K, ap, (long)an, rows, K, sc, st));
     a.A2 = ap; a.a2_plane = (long)an; a.lda2 = K;
   }
@@ -389,14 +399,9 @@ int jv_op_conv_h3_measured(const float* A, int64_t a_rows, int M, int Cin, int n
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t n = (size_t)N * ntaps * Cin;
-  static void* scratch = nullptr;
-  static size_t cap = 0;
+  void* scratch = nullptr;
   const size_t need = n * 10 + (size_t)N * 12 + 512;      // 2 fp16 + 3 bf16 planes, colscale, row stats
-  if (need > cap) {
-    if (scratch) (void)hipFree(scratch);
-    JV_HIP(hipMalloc(&scratch, need));
-    cap = need;
-  }
+  JV_TRY(op_scratch(OPS_CONV, need, &scratch));
   unsigned short* planes2 = static_cast<unsigned short*>(scratch);
   unsigned short* planes3 = planes2 + 2 * n;
   float* cs = reinterpret_cast<float*>(static_cast<char*>(scratch) + ((n * 10 + 63) & ~(size_t)63));
@@ -440,28 +445,18 @@ int jv_op_rowgemm(const float* A, int64_t rows, int M, int K, const float* W, in
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float sc = jv::h3_scale_for_bound(a_bound);
   if (!(sc > 0.f)) return jv::fail(JV_ERR_ARG, "jv_op_rowgemm: unusable bound");
-  static void* scratch = nullptr;
-  static size_t cap = 0;
+  void* scratch = nullptr;
   const size_t n = (size_t)N * K;
   const size_t need = n * 8 + (size_t)N * 12 + 512;
-  if (need > cap) {
-    if (scratch) (void)hipFree(scratch);
-    JV_HIP(hipMalloc(&scratch, need));
-    cap = need;
-  }
+  JV_TRY(op_scratch(OPS_RG, need, &scratch));
   unsigned short* planes = static_cast<unsigned short*>(scratch);
   float* cs = reinterpret_cast<float*>(static_cast<char*>(scratch) + ((n * 4 + 63) & ~(size_t)63));
   JV_TRY(jv::split2h_planes(W, N, K, cs + N, planes, cs, st));
   unsigned short* wf = reinterpret_cast<unsigned short*>(static_cast<char*>(scratch) + ((n * 4 + (size_t)N * 12 + 511) & ~(size_t)255));
   if (!(K & 63)) JV_TRY(jv::pack_wfrag(planes, (long)n, K, N, K, wf, (long)n, st));
-  static unsigned short* ap = nullptr;
-  static size_t acap = 0;
+  unsigned short* ap = nullptr;
   const size_t an = (size_t)rows * K;
-  if (an * 4 > acap) {
-    if (ap) (void)hipFree(ap);
-    JV_HIP(hipMalloc(reinterpret_cast<void**>(&ap), an * 4));
-    acap = an * 4;
-  }
+  JV_TRY(op_scratch(OPS_RG_A, an * 4, reinterpret_cast<void**>(&ap)));
   if (presplit != 2) JV_TRY(jv::split2h_rows(A, K, ap, (long)an, rows, K, sc, st));
   jv::RowGemmArgs a{};
   a.A2 = ap; a.a2_plane = (long)an; a.a_rows = rows; a.lda2 = K;
@@ -483,16 +478,11 @@ int jv_op_rowconv(const float* A, int64_t rows, int M, int Cin, const float* W, 
                   const float* amax_in, float* amax_out, float* out, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int N = 256, K = 3 * Cin;
-  static void* scratch = nullptr;
-  static size_t cap = 0;
+  void* scratch = nullptr;
   const size_t n = (size_t)N * K;
   const size_t head = ((n * 4 + (size_t)N * 12 + 256 + (size_t)rows * sizeof(int)) + 255) & ~(size_t)255;
   const size_t need = head + n * 4;      // + the planes again in fragment order
-  if (need > cap) {
-    if (scratch) (void)hipFree(scratch);
-    JV_HIP(hipMalloc(&scratch, need));
-    cap = need;
-  }
+  JV_TRY(op_scratch(OPS_RC, need, &scratch));
   unsigned short* planes = static_cast<unsigned short*>(scratch);
   float* cs = reinterpret_cast<float*>(static_cast<char*>(scratch) + ((n * 4 + 63) & ~(size_t)63));
   int* slots = reinterpret_cast<int*>(cs + 3 * N + 16);
@@ -519,16 +509,11 @@ int jv_op_hiftconv(const float* A, int64_t rows, int C, int ntaps, int dil, cons
                    const float* amax_in, float a_extra, float* amax_out, float* out, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int K = ntaps * C;
-  static void* scratch = nullptr;
-  static size_t cap = 0;
+  void* scratch = nullptr;
   const size_t n = (size_t)C * K;
   const size_t head = ((n * 4 + (size_t)C * 12 + 256) + 255) & ~(size_t)255;
   const size_t need = head + n * 4;
-  if (need > cap) {
-    if (scratch) (void)hipFree(scratch);
-    JV_HIP(hipMalloc(&scratch, need));
-    cap = need;
-  }
+  JV_TRY(op_scratch(OPS_HIFT, need, &scratch));
   unsigned short* planes = static_cast<unsigned short*>(scratch);
   float* cs = reinterpret_cast<float*>(static_cast<char*>(scratch) + ((n * 4 + 63) & ~(size_t)63));
   unsigned short* wf = reinterpret_cast<unsigned short*>(static_cast<char*>(scratch) + head);
@@ -548,14 +533,8 @@ int jv_op_hiftconv(const float* A, int64_t rows, int C, int ntaps, int dil, cons
 int jv_op_attention_planes(const float* qkv, int64_t rows, const int32_t* lens, int B, int G, int S, int L, float q_bound,
                            float k_bound, float v_bound, int chunk, float out2_scale, float* out, uint16_t* out2, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
-  static unsigned short* kv = nullptr;
-  static size_t cap = 0;
-  const size_t need = (size_t)rows * 1024 * 2 * sizeof(unsigned short);
-  if (need > cap) {
-    if (kv) (void)hipFree(kv);
-    JV_HIP(hipMalloc(reinterpret_cast<void**>(&kv), need));
-    cap = need;
-  }
+  unsigned short* kv = nullptr;
+  JV_TRY(op_scratch(OPS_ATTN, (size_t)rows * 1024 * 2 * sizeof(unsigned short), reinterpret_cast<void**>(&kv)));
   jv::AttnArgs at{};
   at.qkv = qkv; at.ld = 1536; at.out = out; at.ldo = 512;
   at.B = B; at.H = 8; at.G = G; at.S = S; at.L = L; at.lens = lens; at.chunk = chunk;

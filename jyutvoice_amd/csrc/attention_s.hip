@@ -590,10 +590,11 @@ int attention64_single(const AttnArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.L <= 0) return JV_OK;
   if (!a.kv2 || (a.kv_ld & 7) || !(a.q_scale > 0.f && a.k_scale > 0.f && a.v_scale > 0.f) || (a.ld & 3) || (a.ldo & 7) || a.chunk > 0)
     return fail(JV_ERR_ARG, "attention64_single: needs K/V planes, the three scales, aligned strides, no chunk mask");
-  const bool prof = prof_on();
-  if (prof) prof_begin(st);
   int qt = single_qt(a);
   if (const char* f = dyn_env("JV_ATTN_QT")) qt = atoi(f);
+  if (qt < 2 || qt > 5) return fail(JV_ERR_ARG, "attention64_single: bad tile count");      // before the profiler's start event
+  const bool prof = prof_on();
+  if (prof) prof_begin(st);
   switch (qt) {
     case 2: launch_s<2, 2>(a, st); break;
     case 3: launch_s<3, 2>(a, st); break;

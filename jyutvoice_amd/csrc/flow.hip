@@ -236,7 +236,9 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   // The split is a function of K alone (PARTIAL_SPLITS shares of the chunks whenever M <= PARTIAL_ROWS), never of M: the
   // grouping of a row's partial sums must not depend on how many rows the batch has, or a shard would no longer reproduce
   // the whole batch bit for bit (tests/test_gpu_dist.py).
-  const int ksplit = (!c.no_splitk && g.M <= PARTIAL_ROWS) ? PARTIAL_SPLITS : 1;
+  // ... and never together with the row-owning kernels (the debugging override JV_ROWGEMM_RT can force those at short M):
+  // the split-K tails hand the next LayerNorm on as fp32 rows, the row-owning blocks read fp16 planes from the same buffer
+  const int ksplit = (!c.no_splitk && g.M <= PARTIAL_ROWS && rowgemm_tile((int)g.M) == 0) ? PARTIAL_SPLITS : 1;
   // split-K lives in the split-plane kernels (conv_gemm_x6); a launch that would take the fp32-MFMA route (no weight
   // planes, unaligned ldw, JV_NO_X6) runs unsplit instead
   auto splittable = [&](const ConvGemmArgs& a) { return ksplit > 1 && (a.W3 || a.W2) && (a.ldw & 7) == 0 && !dyn_env("JV_NO_X6"); };

@@ -99,3 +99,55 @@ def test_flow_checkpoint_split(tmp_path):
     assert len(rest) == 117 + 12 and all(k.startswith(("encoder.", "dp.")) for k in rest)
     torch.save(enc, tmp_path / "flow_encoder.pt")
     assert set(torch.load(tmp_path / "flow_encoder.pt", weights_only=True)) == set(enc)
+
+
+# ---- the token contract of get_text (infer.py:189-206) -------------------------------------------------
+def test_intersperse_is_the_reference_helper():
+    from jyutvoice_amd.utils.text import intersperse
+    assert intersperse([5, 7, 9], 0) == [0, 5, 0, 7, 0, 9, 0]           # jyutvoice/utils/utils.py:131-135
+    assert intersperse([], 0) == [0]
+    assert intersperse(["a"], "_") == ["_", "a", "_"]
+
+
+def test_get_text_from_ids_matches_get_text():
+    from jyutvoice_amd.utils.text import get_text_from_ids
+    x, xl, tones, wp, sp, lang = get_text_from_ids([12, 96, 3], [1, 6, 2], [1, 2, 3], [3, 0, 1], [0, 1, 2])
+    assert x.tolist() == [[0, 12, 0, 96, 0, 3, 0]] and xl.tolist() == [7] and x.dtype == torch.int64
+    assert tones.tolist() == [[0, 1, 0, 6, 0, 2, 0]] and lang.tolist() == [[0, 0, 0, 1, 0, 2, 0]]
+    assert wp.shape == sp.shape == (1, 7)
+    # the synthetic utterances obey the same contract (odd lengths: blank first and last)
+    from jyutvoice_amd.utils.text import validate_ids
+    u = synth.batch(1, 13)
+    assert validate_ids({k: u[k][0].tolist() for k in ("x", "lang", "tone", "word_pos", "syllable_pos")}) == 13
+
+
+@pytest.mark.parametrize("edit, message", [
+    (lambda t: t.__setitem__("tone", t["tone"][:-1]), "equal length"),
+    (lambda t: t["x"].__setitem__(1, 97), "outside [0, 97)"),
+    (lambda t: t["tone"].__setitem__(1, 7), "outside [0, 7)"),
+    (lambda t: t["lang"].__setitem__(1, 4), "outside [0, 4)"),
+    (lambda t: t["word_pos"].__setitem__(3, -1), "outside [0, 4)"),
+    (lambda t: t["syllable_pos"].__setitem__(3, 4), "outside [0, 4)"),
+    (lambda t: t["x"].__setitem__(2, 5), "even positions hold the blank"),
+    (lambda t: t["x"].__setitem__(1, 1.5), "not an integer"),
+    (lambda t: t.pop("lang"), "missing id lists"),
+    (lambda t: [t[k].append(0) for k in list(t)], "odd length"),
+])
+def test_tokens_json_violations_are_named(edit, message):
+    from jyutvoice_amd.utils.text import load_tokens_json
+    tok = {"x": [0, 12, 0, 96, 0], "lang": [0, 1, 0, 3, 0], "tone": [0, 6, 0, 1, 0], "word_pos": [0, 3, 0, 1, 0],
+           "syllable_pos": [0, 2, 0, 3, 0]}
+    ok = load_tokens_json(tok)
+    assert ok["x"].shape == (1, 5) and ok["x_lengths"].tolist() == [5]
+    edit(tok)
+    with pytest.raises(ValueError) as e:
+        load_tokens_json(tok)
+    assert message in str(e.value)
+
+
+def test_tokens_json_raw_lists_get_their_blanks():
+    from jyutvoice_amd.utils.text import load_tokens_json
+    out = load_tokens_json({"interspersed": False, "x": [12, 96], "lang": [1, 3], "tone": [6, 1], "word_pos": [3, 1], "syllable_pos": [2, 3]})
+    assert out["x"].tolist() == [[0, 12, 0, 96, 0]] and out["x_lengths"].tolist() == [5] and out["lang"].tolist() == [[0, 1, 0, 3, 0]]
+    with pytest.raises(ValueError):
+        load_tokens_json({"interspersed": False, "x": [], "lang": [], "tone": [], "word_pos": [], "syllable_pos": []})

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Build-time check of the hand-managed register double buffer of the W-direct kernels: rowgemm_wd_kernel, rowgemm_wa_kernel,
-rowffn_kernel (rowgemm_kernel.h), rowconv_wd_kernel (rowconv_kernel.h) and rowblock_kernel (rowblock_kernel.h).
+rowffn_kernel (rowgemm_kernel.h), rowconv_wd_kernel (rowconv_kernel.h), rowblock_kernel (rowblock_kernel.h) and hiftconv_kernel
+(hiftconv_kernel.h: the vocoder's 72 ResBlock convolutions).
 
 The weight fragments are loaded by inline asm (global_load_dwordx4) and waited for by a counted s_waitcnt the compiler does
 not know about.  That is only sound if, in the generated code, the destination registers of those loads are touched by
 nothing except (a) the asm loads, (b) v_mfma instructions reading them as an operand, (c) code ahead of the register's
 first load (the straight-line prologue, where nothing is in flight in it yet).  A register-allocator copy or spill of one of them while a load is in flight would read stale data without
-any tool noticing.  This script compiles rowgemm.hip and rowblock.hip to assembly and asserts exactly that for every instantiation.
+any tool noticing.  This script compiles rowgemm.hip, rowblock.hip and hiftconv.hip to assembly and asserts exactly that for every instantiation.
 
 Second check, attention_s.hip (attn64_s_kernel): that kernel keeps its O accumulators and high Q planes in AGPRs it names
 itself inside inline asm (a32 and up), without telling the compiler.  Sound only if the compiler-generated code of the kernel
@@ -20,10 +21,13 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRCS = [os.path.join(ROOT, "jyutvoice_amd", "csrc", f) for f in ("rowgemm.hip", "rowblock.hip")]
+SRCS = [os.path.join(ROOT, "jyutvoice_amd", "csrc", f) for f in ("rowgemm.hip", "rowblock.hip", "hiftconv.hip")]
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 ATTN_S = os.path.join(ROOT, "jyutvoice_amd", "csrc", "attention_s.hip")
-FLAGS0 = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-fno-slp-vectorize", "-x", "hip", "--cuda-device-only", "-S"]
+sys.path.insert(0, ROOT)
+from jyutvoice_amd.build import FILE_FLAGS, FLAGS as LIB_FLAGS      # exactly the flags the library is built with (-fPIC, JV_EXTRA_FLAGS, ...)
+
+FLAGS0 = list(LIB_FLAGS) + ["-x", "hip", "--cuda-device-only", "-S"]
 
 REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
 
@@ -127,8 +131,6 @@ def check_agpr_owner(name, body):
 
 def main():
     s = ""
-    sys.path.insert(0, ROOT)
-    from jyutvoice_amd.build import FILE_FLAGS      # the per-file flags the library is built with
     with tempfile.TemporaryDirectory() as d:
         for src, extra in [(f, []) for f in SRCS + [ATTN_S]] + [(ATTN_S, ["-DJV_TUNING"])]:      # (the tuning build's variants too)
             out = os.path.join(d, os.path.basename(src) + (".tune" if extra else "") + ".s")
@@ -145,7 +147,7 @@ def main():
                 print(r.stderr[-3000:])
                 return 2
     n_k = n_bad = 0
-    for m in re.finditer(r"^(_ZN2jv\d+(rowgemm_wd_kernel|rowgemm_wa_kernel|rowffn_kernel|rowconv_wd_kernel|rowblock_kernel)\w+):\s*;.*?\n(.*?)\.end_amdhsa_kernel", s, re.S | re.M):
+    for m in re.finditer(r"^(_ZN2jv\d+(rowgemm_wd_kernel|rowgemm_wa_kernel|rowffn_kernel|rowconv_wd_kernel|rowblock_kernel|hiftconv_kernel)\w+):\s*;.*?\n(.*?)\.end_amdhsa_kernel", s, re.S | re.M):
         name, body = m.group(1), m.group(3)
         body = body.split("s_endpgm")[0]
         n_loads, bad = check_kernel(name, body)
