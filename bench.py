@@ -74,6 +74,20 @@ def kernel_peak(name: str):
     return FP32_MFMA_PEAK_TFLOPS, "fp32 inputs, fp32 accumulate (v_mfma_f32_32x32x2_f32); peak = dense fp32 MFMA"
 
 
+def path_flops(workload: str, utt_tokens, n_steps: int) -> float:
+    """Algorithmic FLOP (2 x multiply-add) of one pass, SURVEY.md 8(d): per utterance of Tt tokens -> T = 2 Tt frames,
+      flow estimator, per frame and Euler step, CFG x2:  2 * 2 * (7 360 512 convs + 58 720 256 linears + 57 344 T attention)
+      HiFT:     612.3 MFLOP per mel frame
+      encoder + duration predictor:  (52.354 M + 6 layers * 2 * 2 * 576 * Tt attention) per token  (= 52.7 M at Tt = 150)"""
+    total = 0.0
+    for tt in utt_tokens:
+        t = 2 * tt
+        total += n_steps * t * 2.0 * 2.0 * (7360512.0 + 58720256.0 + 57344.0 * t)
+        if workload == "c3":
+            total += 612.3e6 * t + tt * (52.354e6 + 6 * 2304.0 * tt)
+    return total
+
+
 def host_cores() -> int:
     """CPU threads this process may really use: cgroup quota if any, else the affinity mask, capped at the GPU box's
     documented 16-core share when neither says less."""
@@ -192,6 +206,10 @@ def main():
                     help="strong scaling: --total-batch utterances over ALL ranks (BASELINE.json configs[4] as written: 256 over 8 "
                          "GPUs) instead of --batch per rank")
     ap.add_argument("--total-batch", type=int, default=256)
+    ap.add_argument("--ragged", action="store_true",
+                    help="utterances of seeded, unequal lengths: token counts uniform in [--ragged-min, --tokens] (one of them "
+                         "--tokens, so the padded shape is the equal-length run's); `value` counts VALID frames only")
+    ap.add_argument("--ragged-min", type=int, default=60)
     args = ap.parse_args()
 
     import torch
@@ -231,13 +249,20 @@ def main():
     hift.load_state_dict(synth.hift_state_dict())
     hift.manual_seed(1234 + rank)
     lo, _ = jdist.shard_range(args.total_batch if args.strong else B * world, rank, world)
-    batch = {k: v.to(device) for k, v in synth.batch(B, Tt, first_index=lo).items()}
+    utt_tokens = [Tt] * B
+    if args.ragged:      # real batches are ragged (jyutvoice/utils/mask.py:232-255 pads them to the longest)
+        gl = torch.Generator().manual_seed(4321 + rank)
+        utt_tokens = torch.randint(args.ragged_min, Tt + 1, (B,), generator=gl).tolist()
+        utt_tokens[int(torch.randint(0, B, (1,), generator=gl))] = Tt
+    batch = {k: v.to(device) for k, v in synth.batch(B, Tt, first_index=lo, lengths=utt_tokens).items()}
+    valid_frames = 2 * sum(utt_tokens)      # fixed_duration = 1.5: two frames per token
 
     if args.workload == "c2":     # mu ~ N(0,1) [B,80,T], spks ~ N(0,1), cond = 0, full mask
         gen = torch.Generator().manual_seed(1234 + rank)
         c2_mu = torch.randn(B, 80, T, generator=gen).to(device)
         c2_spks = torch.randn(B, 80, generator=gen).to(device)
         c2_cond = torch.zeros(B, 80, T, device=device)
+        c2_lens = torch.tensor([2 * t for t in utt_tokens], dtype=torch.int32, device=device) if args.ragged else None
         eng = get_runtime(device).ensure(B, T, Tt)
 
     src = {}
@@ -246,11 +271,11 @@ def main():
         """one pass; gather=False leaves out the end-of-step collective (passes that only SOME ranks run, outside the timed
         region: a collective entered by rank 0 alone would wait for the others forever)"""
         if args.workload == "c2":
-            mel = eng.cfm_solve(c2_mu, None, c2_spks, c2_cond, n_steps, 1.0)
+            mel = eng.cfm_solve(c2_mu, c2_lens, c2_spks, c2_cond, n_steps, 1.0)
             return {"mel": mel, "mel_lengths": None}, None
         res = tts.synthesise(batch["x"], batch["x_lengths"], batch["lang"], batch["tone"], batch["word_pos"],
                              batch["syllable_pos"], batch["spk_embed"], None, n_timesteps=n_steps, batched=True)
-        wav, src["s"] = hift.inference(res["mel"])
+        wav, src["s"] = hift.inference(res["mel"], lengths=res["mel_lengths"] if args.ragged else None)
         if use_dist and gather:
             if coll_dev == "cpu":      # gloo rehearsal: host tensors
                 jdist.all_gather_mels(res["mel"].cpu(), res["mel_lengths"].cpu())
@@ -341,6 +366,8 @@ def main():
 
     if rank == 0:
         frames = (args.total_batch if args.strong else world * B) * T * args.steps
+        if args.ragged:      # every rank draws its own lengths from the same distribution; rank 0's sum stands for each
+            frames = world * valid_frames * args.steps
         out = {
             "metric": "mel_frames_per_sec", "value": round(frames / elapsed, 1), "unit": "mel-frames/s",
             "rtf": round(elapsed / (frames * 0.02), 6), "x_realtime": round(frames * 0.02 / elapsed, 1),
@@ -357,6 +384,18 @@ def main():
                                        "fp32-accurate split-plane MFMA: fp16x3 on the estimator's range-proven linears and "
                                        "attention, bf16x6 elsewhere (DESIGN.md 5; JV_EXACT_RANGE=1 forces bf16x6)")},
         }
+        if args.ragged:
+            out["config"]["ragged"] = {"tokens_min": min(utt_tokens), "tokens_max": max(utt_tokens), "valid_frames_per_gpu": valid_frames,
+                                       "padded_frames_per_gpu": B * T, "fill": round(valid_frames / (B * T), 4),
+                                       "note": "`value` counts valid frames only; lengths ~ U[--ragged-min, --tokens], seeded"}
+        # the whole path against the engine's ceiling: algorithmic FLOP of a pass / wall time / (2500 / 3)
+        pf = path_flops(args.workload, utt_tokens, n_steps) * (args.total_batch / B if args.strong else world)
+        ptf = pf * args.steps / elapsed / 1e12
+        out["roofline_path"] = {"bound": "mfma", "alg_tflop_per_pass": round(pf / 1e12, 3), "achieved": round(ptf, 2),
+                                "peak": round(world * BF16_MFMA_PEAK_TFLOPS / 3.0, 1), "unit": "TFLOP/s",
+                                "frac": round(ptf / (world * BF16_MFMA_PEAK_TFLOPS / 3.0), 4),
+                                "note": "every contraction of the pass (SURVEY.md 8(d) formulas) over the wall time of the timed loop, "
+                                        "against the fp16x3 ceiling (dense fp16 MFMA / 3) of the GPUs used"}
         if stage_ms:
             out["stage_ms"] = stage_ms
         groups = {k[len("_group:"):]: kern.pop(k) for k in [k for k in kern if k.startswith("_group:")]}
@@ -414,7 +453,7 @@ def main():
             out["exact_range_note"] = ("the same timed loop, under the same conditions (first step instrumented), with every "
                                        "contraction on bf16x6 (24-bit operands, jv_flow_set_contraction(1)); `value` is the default fp16x3 mode")
         parity_ok = True
-        if world == 1 and not args.no_cpu_baseline and args.cpu_utts > 0 and args.workload == "c3":
+        if world == 1 and not args.no_cpu_baseline and args.cpu_utts > 0 and args.workload == "c3" and not args.ragged:
             out["cpu_baseline"], parity = cpu_baseline(Tt, n_steps, args.cpu_utts, hip_out)
             if parity:
                 out["parity"] = parity

@@ -109,6 +109,13 @@ int jv_flow_set_graph(jv_context* ctx, int on);
  * Both meet the same operator-level bound against fp64 (tests/test_gpu_ops.py).  Applies to this context's estimator,
  * solver and vocoder calls. */
 int jv_flow_set_contraction(jv_context* ctx, int exact_range);
+/* jv_flow_contraction_info: what the load-time range proofs of the last jv_finalize(JV_MODEL_TTS) concluded for the
+ * estimator's 56 transformer blocks (transformer.py:355-443; registry.hip), so that a caller -- or a test with a hostile
+ * checkpoint -- can see which layers took the fp16x3 engine and which stayed on bf16x6 because their bound was unusable
+ * (non-finite or beyond 1e30).  out[0] = blocks, out[1] = blocks whose four linears AND attention all have a usable bound,
+ * out[2] = linears (of 4 per block) with a usable bound, out[3] = blocks whose attention operands (q, k, v) have one.
+ * n = number of int32 slots in out (>= 4). */
+int jv_flow_contraction_info(const jv_context* ctx, int32_t* out, int n);
 /* jv_cfm_solve: CausalConditionalCFM.forward + ConditionalCFM.solve_euler (flow_matching.py:356-401, 215-265):
  * fixed noise prefix * temperature, cosine schedule, n_timesteps Euler steps with CFG rate 0.7.
  * mu, cond, mel: [B,80,T]; spks: [B,80]; lens: [B] int32 or NULL.  t_span_host: optional n_timesteps+1 host floats
@@ -161,6 +168,13 @@ int jv_length_regulate(jv_context* ctx, const float* logw, const int64_t* x_leng
 int jv_hift_f0(jv_context* ctx, const float* mel, const int32_t* lens, int B, int T, float* f0, void* stream);
 int jv_hift_source(jv_context* ctx, const float* f0, const float* phase, const float* noise, int B, int T, float* s,
                    void* stream);
+/* jv_hift_source_seeded: the same with the noise drawn INSIDE the kernel -- generator.py:171 (`torch.randn_like`) draws
+ * values no caller can depend on, and a [B,9,480T] tensor written by one kernel only to be read once by the next is 166 MB
+ * per pass at the headline size.  Each sample's nine N(0,1) draws are Philox4x32-10 + Box-Muller of (seed, call, utterance,
+ * sample): reproducible for a given (seed, call), independent across calls (the caller counts them).  Parity tests inject the
+ * oracle's noise through jv_hift_source instead. */
+int jv_hift_source_seeded(jv_context* ctx, const float* f0, const float* phase, uint64_t seed, uint32_t call, int B, int T, float* s,
+                          void* stream);
 int jv_hift_decode(jv_context* ctx, const float* mel, const float* s, const int32_t* lens, int B, int T, float* wav,
                    void* stream);
 

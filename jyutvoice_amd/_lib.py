@@ -52,6 +52,7 @@ SIGNATURES = {
     "jv_flow_set_streaming": (_i, [_p, _i]),
     "jv_flow_set_graph": (_i, [_p, _i]),
     "jv_flow_set_contraction": (_i, [_p, _i]),
+    "jv_flow_contraction_info": (_i, [_p, _p, _i]),
     "jv_cfm_solve": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
     "jv_encoder_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
     "jv_load_mel_basis": (_i, [_p, _p, _i64, _i, _p]),
@@ -60,6 +61,7 @@ SIGNATURES = {
     "jv_length_regulate": (_i, [_p, _p, _p, _p, _i, _i, _f, _p, _p, _i, _p, _p, _p]),
     "jv_hift_f0": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "jv_hift_source": (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
+    "jv_hift_source_seeded": (_i, [_p, _p, _p, C.c_uint64, C.c_uint32, _i, _i, _p, _p]),
     "jv_hift_decode": (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
     "jv_op_conv_gemm": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _f, _p, _p, _f, _p, _p, _p, _p]),
     "jv_op_attention": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),

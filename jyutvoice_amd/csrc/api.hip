@@ -305,6 +305,22 @@ int jv_flow_set_contraction(jv_context* ctx, int exact_range) {
   return JV_OK;
 }
 
+int jv_flow_contraction_info(const jv_context* ctx, int32_t* out, int n) {
+  if (!ctx || !out || n < 4) return jv::fail(JV_ERR_ARG, "jv_flow_contraction_info: null argument or fewer than 4 slots");
+  if (!ctx->c.ready[jv::MODEL_TTS]) return jv::fail(JV_ERR_STATE, "tts weights not finalized");
+  int blocks = 0, all = 0, lin = 0, att = 0;
+  for (int i = 0; i < jv::EST_NRES; ++i)
+    for (int j = 0; j < jv::EST_NBLK; ++j) {
+      const jv::BtbW& b = ctx->c.est.blk[i][j];
+      const int l = (b.qkv.w2 && b.qkv.a_scale > 0.f) + (b.out.w2 && b.out.a_scale > 0.f) + (b.ff1.w2 && b.ff1.a_scale > 0.f) +
+                    (b.ff2.w2 && b.ff2.a_scale > 0.f);
+      const bool a = b.q_scale > 0.f && b.k_scale > 0.f && b.v_scale > 0.f;
+      ++blocks; lin += l; att += a; all += (l == 4 && a);
+    }
+  out[0] = blocks; out[1] = all; out[2] = lin; out[3] = att;
+  return JV_OK;
+}
+
 int jv_cfm_solve(jv_context* ctx, const float* mu, const int32_t* lens, const float* spks, const float* cond, int B, int T,
                  int n_timesteps, float temperature, const float* t_span_host, float* mel, void* stream) {
   CTX_GUARD(ctx);

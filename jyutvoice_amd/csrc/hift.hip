@@ -20,7 +20,7 @@ int hiftconv(const HiftConvArgs& a, int C, hipStream_t st);      // hiftconv.hip
 
 int f0_head(const float* h, const float* w, const float* bias, float* f0, int B, int T, int G, int S, hipStream_t st);
 int sine_source(const float* f0, const float* phase, const float* noise, const float* lin_w, const float* lin_b, float* frac,
-                float* s, int B, int T, hipStream_t st);
+                float* s, int B, int T, hipStream_t st, unsigned long long seed, unsigned call);
 int stft_rows(const float* s, float* out, const int* lens, int B, int T, int G3, int S3, long rows, hipStream_t st);
 int reflect_fix(float* x, int B, int G3, int S3, int C, hipStream_t st);
 int istft_head(const float* post, float* frames, float* wav, const int* lens, int B, int T, int G3, int S3, long rows,
@@ -239,9 +239,11 @@ int hift_f0(Context& c, const float* mel, const int* lens, int B, int T, float* 
   return f0_head(in, c.hift.f0_cls_w, c.hift.f0_cls_b, f0, B, T, H_G0, g.S0, st);
 }
 
-int hift_source(Context& c, const float* f0, const float* phase, const float* noise, int B, int T, float* s, hipStream_t st) {
+// noise == nullptr: the N(0,1) draws are generated inside source_mix from (seed, call) -- hiftops.hip
+int hift_source(Context& c, const float* f0, const float* phase, const float* noise, int B, int T, float* s, hipStream_t st,
+                unsigned long long seed = 0, unsigned call = 0) {
   JV_TRY(check(c, B, T));
-  return sine_source(f0, phase, noise, c.hift.src_lin_w, c.hift.src_lin_b, c.hws->frac, s, B, T, st);
+  return sine_source(f0, phase, noise, c.hift.src_lin_w, c.hift.src_lin_b, c.hws->frac, s, B, T, st, seed, call);
 }
 
 int hift_decode(Context& c, const float* mel, const float* s, const int* lens, int B, int T, float* wav, hipStream_t st) {
@@ -324,6 +326,13 @@ int jv_hift_source(jv_context* ctx, const float* f0, const float* phase, const f
   if (!ctx || !f0 || !phase || !noise || !s) return jv::fail(JV_ERR_ARG, "jv_hift_source: null argument");
   JV_HIP(hipSetDevice(ctx->c.device));
   return jv::hift_source(ctx->c, f0, phase, noise, B, T, s, static_cast<hipStream_t>(stream));
+}
+
+int jv_hift_source_seeded(jv_context* ctx, const float* f0, const float* phase, uint64_t seed, uint32_t call, int B, int T, float* s,
+                          void* stream) {
+  if (!ctx || !f0 || !phase || !s) return jv::fail(JV_ERR_ARG, "jv_hift_source_seeded: null argument");
+  JV_HIP(hipSetDevice(ctx->c.device));
+  return jv::hift_source(ctx->c, f0, phase, nullptr, B, T, s, static_cast<hipStream_t>(stream), seed, call);
 }
 
 int jv_hift_decode(jv_context* ctx, const float* mel, const float* s, const int32_t* lens, int B, int T, float* wav,

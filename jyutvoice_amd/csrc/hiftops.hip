@@ -95,11 +95,38 @@ __global__ void sine_frame_scan_kernel(const float* __restrict__ f0, double* __r
   }
 }
 
+// Philox4x32-10 (Salmon et al., SC'11): the counter-based generator behind the seeded source noise -- a sample's nine draws
+// are a pure function of (seed, call, utterance, sample), so no 9 x 480 T noise tensor is written and read back
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// two uniform words -> two N(0,1) draws (Box-Muller; u1 in (0, 1] so the logarithm is finite)
+__device__ __forceinline__ void box_muller(unsigned a, unsigned b, float& z0, float& z1) {
+  const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+  const float r = sqrtf(-2.0f * __logf(u1));
+  float sn, cs;
+  __sincosf(6.283185307179586f * u2, &sn, &cs);
+  z0 = r * cs;
+  z1 = r * sn;
+}
+
 // s[b,n] = tanh( lin_b + sum_h lin_w[h] * ( 0.1 sin(2 pi frac + phi_h) * uv + namp * noise ) )
+// noise == nullptr: the nine N(0,1) draws of a sample come from Philox keyed by (seed_lo, seed_hi), counter (utterance,
+// sample, call, 3 blocks) -- generator.py:171 draws them with torch.randn_like, whose values no caller can depend on
 __global__ __launch_bounds__(256) void source_mix_kernel(const float* __restrict__ f0, const double* __restrict__ start,
                                                          const float* __restrict__ phase, const float* __restrict__ noise,
                                                          const float* __restrict__ lin_w, const float* __restrict__ lin_b,
-                                                         float* __restrict__ s, int B, int T) {
+                                                         float* __restrict__ s, int B, int T, unsigned seed_lo, unsigned seed_hi,
+                                                         unsigned call) {
   const long n_per = (long)T * 480;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n_per * B) return;
@@ -109,6 +136,16 @@ __global__ __launch_bounds__(256) void source_mix_kernel(const float* __restrict
   const float f = f0[b * T + t];
   const float uv = f > 10.0f ? 1.f : 0.f;
   const float namp = uv * 0.003f + (1.f - uv) * 0.1f / 3.f;
+  float z[12];
+  if (!noise) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      unsigned r[4];
+      philox4x32_10((unsigned)n, (unsigned)b, call, (unsigned)j, seed_lo, seed_hi, r);
+      box_muller(r[0], r[1], z[4 * j], z[4 * j + 1]);
+      box_muller(r[2], r[3], z[4 * j + 2], z[4 * j + 3]);
+    }
+  }
   float acc = 0.f;
 #pragma unroll
   for (int h = 0; h < 9; ++h) {
@@ -126,18 +163,18 @@ __global__ __launch_bounds__(256) void source_mix_kernel(const float* __restrict
     const float theta = 2.0f * 3.14159265358979323846f * frac;
     const float ph = h == 0 ? 0.f : phase[b * 9 + h];
     const float sine = 0.1f * sinf(theta + ph);
-    acc += (sine * uv + namp * noise[((long)b * 9 + h) * n_per + n]) * lin_w[h];
+    acc += (sine * uv + namp * (noise ? noise[((long)b * 9 + h) * n_per + n] : z[h])) * lin_w[h];
   }
   s[idx] = tanhf(acc + lin_b[0]);
 }
 
 int sine_source(const float* f0, const float* phase, const float* noise, const float* lin_w, const float* lin_b, float* frac,
-                float* s, int B, int T, hipStream_t st) {
+                float* s, int B, int T, hipStream_t st, unsigned long long seed, unsigned call) {
   // `frac` (sized [B, 9, 480 T] floats by hift_ws_create) now only holds the [B, 9, T] frame-start sums, as doubles
   double* start = reinterpret_cast<double*>(frac);
   hipLaunchKernelGGL(sine_frame_scan_kernel, dim3(cdiv(B * 9, 64)), dim3(64), 0, st, f0, start, B, T);
   hipLaunchKernelGGL(source_mix_kernel, dim3((unsigned)cdivl((long)B * T * 480, 256)), dim3(256), 0, st, f0, start, phase, noise,
-                     lin_w, lin_b, s, B, T);
+                     lin_w, lin_b, s, B, T, (unsigned)seed, (unsigned)(seed >> 32), call);
   JV_HIP(hipGetLastError());
   return JV_OK;
 }

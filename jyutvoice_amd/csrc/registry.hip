@@ -631,14 +631,20 @@ int finalize_model(Context& c, int model, hipStream_t st) {
         w.k_scale = h3_scale_for_bound(l1_k * b1);
         w.v_scale = h3_scale_for_bound(l1_v * b1);
         if (!(w.q_scale > 0.f && w.k_scale > 0.f && w.v_scale > 0.f)) w.q_scale = w.k_scale = w.v_scale = 0.f;
-        v_bound = fmaxf(v_bound, l1_v * b1);
-        if (!(l1_v * b1 < 1e30f)) v_bound = INFINITY;
+        // a block whose V bound is unusable (non-finite, or beyond 1e30: h3_scale_for_bound) keeps its attention and its
+        // to_out on bf16x6 and does not enter the shared scale below: one hostile layer costs that layer (and the row-owning
+        // kernels of its stage, flow.hip stage_all_rg), not the engine of the other 55 blocks
+        w.out.a_scale = (w.v_scale > 0.f && l1_v * b1 < 1e30f) ? 1.f : 0.f;      // (1 = "usable", replaced below)
+        if (w.out.a_scale > 0.f) v_bound = fmaxf(v_bound, l1_v * b1);
       }
     }
     // the attention buffer is shared by all 56 blocks (and keeps rows of earlier calls between the utterances' windows):
-    // one scale from the largest V bound
+    // one scale from the largest usable V bound.  (Every kernel on the path is row-local -- an output row depends on its own
+    // input row alone -- and masked rows are never tracked or staged, so whatever an fp32-writing block leaves in the gap
+    // rows stays there.)
     for (int i = 0; i < EST_NRES; ++i)
-      for (int j = 0; j < EST_NBLK; ++j) e.blk[i][j].out.a_scale = h3_scale_for_bound(v_bound);
+      for (int j = 0; j < EST_NBLK; ++j)
+        if (e.blk[i][j].out.a_scale > 0.f) e.blk[i][j].out.a_scale = h3_scale_for_bound(v_bound);
     flow_ws_forget_attention(c, st);
     e.temb_all = pk.concat(tw, tb, EST_CH, EST_TIME);
     e.down_conv = pk.conv_named(p + "down_blocks.0.2.", EST_CH, EST_CH, 3);

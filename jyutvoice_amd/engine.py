@@ -121,6 +121,13 @@ class Engine:
         at load time (jv_flow_set_contraction)"""
         check(self.lib.jv_flow_set_contraction(self._h, 1 if on else 0))
 
+    def contraction_info(self) -> dict:
+        """which of the estimator's transformer layers have a usable load-time bound (fp16x3) and which stay on bf16x6
+        (jv_flow_contraction_info)"""
+        out = (C.c_int32 * 4)()
+        check(self.lib.jv_flow_contraction_info(self._h, out, 4))
+        return {"blocks": out[0], "blocks_all_h3": out[1], "linears_h3": out[2], "attention_h3": out[3]}
+
     def flow_estimator(self, x, mask_lens, mu, t, spks, cond):
         """[B2,80,T] tensors on the device; mask_lens int32 [B2] or None."""
         B2, _, T = x.shape
@@ -212,6 +219,15 @@ class Engine:
         f0, phase, noise = _f32(f0, self.device), _f32(phase, self.device), _f32(noise, self.device)
         s = torch.empty(B, 1, T * spec.HIFT_UPSAMPLE_TOTAL, device=self.device)
         check(self.lib.jv_hift_source(self._h, _ptr(f0), _ptr(phase), _ptr(noise), B, T, _ptr(s), _stream(self.device)))
+        return s
+
+    def hift_source_seeded(self, f0, phase, seed: int, call: int):
+        """the source signal with its N(0,1) noise drawn inside the kernel from (seed, call) -- no [B,9,480T] noise tensor"""
+        B, T = f0.shape
+        f0, phase = _f32(f0, self.device), _f32(phase, self.device)
+        s = torch.empty(B, 1, T * spec.HIFT_UPSAMPLE_TOTAL, device=self.device)
+        check(self.lib.jv_hift_source_seeded(self._h, _ptr(f0), _ptr(phase), C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint32(call & 0xFFFFFFFF),
+                                             B, T, _ptr(s), _stream(self.device)))
         return s
 
     def hift_decode(self, mel, s, lens=None):

@@ -3,8 +3,11 @@ state-dict key names (both weight-norm spellings), `inference(speech_feat, cache
 `decode(x, s)`.  All arithmetic runs in libjyutvoice_hip.so (jv_hift_f0 / jv_hift_source / jv_hift_decode).
 
 The reference's sine generator draws Uniform(-pi, pi) phases and N(0,1) noise per call (generator.py:155-158,
-171), so `inference` is stochastic there too; here the draws come from a torch generator on the GPU
-(`seed=` makes them repeatable) and are handed to the library, which never owns RNG state."""
+171), so `inference` is stochastic there too; here the nine phases per utterance come from a torch generator on the GPU and
+the per-sample N(0,1) noise from a counter-based generator INSIDE the source kernel (jv_hift_source_seeded: Philox keyed by
+the seed, counted per call -- `manual_seed` makes both repeatable), so the 9 x 480 T noise tensor is never materialised.
+The library owns no RNG state: (seed, call) are arguments.  `Engine.hift_source(f0, phase, noise)` (jv_hift_source) injects a
+caller's draws instead -- what the parity tests do with the oracle's."""
 from __future__ import annotations
 
 import math
@@ -42,6 +45,8 @@ class HiFTGenerator:
         self.device = torch.device(device)
         self._loaded = False
         self._gen: Optional[torch.Generator] = None
+        self._seed: Optional[int] = None      # of the in-kernel source noise; drawn on first use unless manual_seed() set it
+        self._calls = 0
 
     def to(self, device):
         self.device = torch.device(device)
@@ -53,6 +58,7 @@ class HiFTGenerator:
     def manual_seed(self, seed: int):
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(seed)
+        self._seed, self._calls = int(seed), 0
         return self
 
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
@@ -89,8 +95,10 @@ class HiFTGenerator:
         eng = self._engine(B, T)
         f0 = eng.hift_f0(speech_feat, lengths)
         phase = (torch.rand(B, 9, device=self.device, generator=self._gen) * 2 - 1) * math.pi
-        noise = torch.randn(B, 9, T * spec.HIFT_UPSAMPLE_TOTAL, device=self.device, generator=self._gen)
-        s = eng.hift_source(f0, phase, noise)
+        if self._seed is None:      # (a host draw: no device synchronisation)
+            self._seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        s = eng.hift_source_seeded(f0, phase, self._seed, self._calls)
+        self._calls += 1
         if cache_source.shape[2] != 0:
             s[:, :, : cache_source.shape[2]] = cache_source.to(self.device)
         return eng.hift_decode(speech_feat, s, lengths), s

@@ -21,6 +21,7 @@ def time_embedding(sd, t, pre, dim=320, scale=1000.0):
     f = torch.exp(torch.arange(half).float() * -(math.log(10000) / (half - 1)))
     e = scale * t.unsqueeze(1) * f.unsqueeze(0)
     e = torch.cat([e.sin(), e.cos()], dim=-1)
+    e = e.to(sd[pre + "time_mlp.linear_1.weight"].dtype)      # (no-op in fp32; lets tests evaluate the same model in fp64)
     e = F.linear(e, sd[pre + "time_mlp.linear_1.weight"], sd[pre + "time_mlp.linear_1.bias"])
     e = F.silu(e)
     return F.linear(e, sd[pre + "time_mlp.linear_2.weight"], sd[pre + "time_mlp.linear_2.bias"])

@@ -621,6 +621,34 @@ def test_attention_rows(dev, monkeypatch, B, L, lens, qt, form):
         assert torch.equal(op_attention_planes(qkv.to(dev), lens_t.to(dev), B, G, S, L, bounds), first), i
 
 
+@pytest.mark.parametrize("B,L,lens", [(2, 300, [300, 217]), (3, 70, [70, 1, 33]), (2, 129, [129, 64]), (2, 320, [320, 299])])
+def test_attention_single_equals_planes_bit_for_bit(dev, monkeypatch, B, L, lens):
+    """attn64_s (attention_s.hip, one wave per SIMD) and attn64_pl (attention_pl.hip, the DMA-ring form) are chosen by batch
+    size (flow.hip: attention64_single_fits): an utterance's mel must not depend on which one its batch got, so the two must
+    agree BIT FOR BIT -- same lazy reference maximum, same summation order -- on the fp32 output and on the fp16-plane output
+    the pipeline takes, with ragged key masks."""
+    from jyutvoice_amd.engine import op_attention_planes
+    g = torch.Generator().manual_seed(B * 977 + L)
+    G, gap = 4, 4
+    S = L + gap
+    rows = G + B * S + 8
+    qkv = torch.randn(rows, 1536, generator=g)
+    qkv[:, 512:1024] *= 3.0
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    bounds = tuple(4.0 * float(qkv[:, o:o + 512].abs().max()) for o in (0, 512, 1024))
+    monkeypatch.delenv("JV_OP_ATTN_SINGLE", raising=False)
+    monkeypatch.delenv("JV_OP_ATTN_ROWS", raising=False)
+    pl32 = op_attention_planes(qkv.to(dev), lens_t.to(dev), B, G, S, L, bounds).cpu()
+    pl16 = op_attention_planes(qkv.to(dev), lens_t.to(dev), B, G, S, L, bounds, planes_out=True).cpu()
+    monkeypatch.setenv("JV_OP_ATTN_SINGLE", "1")
+    s32 = op_attention_planes(qkv.to(dev), lens_t.to(dev), B, G, S, L, bounds).cpu()
+    s16 = op_attention_planes(qkv.to(dev), lens_t.to(dev), B, G, S, L, bounds, planes_out=True).cpu()
+    for b in range(B):
+        sl = slice(G + b * S, G + b * S + L)      # (rows between the utterances are not written by either form)
+        assert torch.equal(pl32[sl], s32[sl]), b
+        assert torch.equal(pl16[sl], s16[sl]), b
+
+
 @pytest.mark.parametrize("k,dil,C,rows", [(11, 5, 64, 1500), (7, 3, 128, 700), (3, 1, 256, 333), (11, 5, 256, 250), (7, 1, 64, 321),
                                           (3, 5, 128, 161), (11, 1, 128, 40)])
 def test_hiftconv(dev, k, dil, C, rows):

@@ -101,6 +101,37 @@ def test_hift_source_long_and_unvoiced(eng, hift_sd):
     assert md(s, want) <= 2e-5
 
 
+def test_hift_source_seeded_noise_is_standard_normal(eng, hift_sd):
+    """jv_hift_source_seeded draws the nine N(0,1) values of a sample inside the kernel (Philox4x32-10 + Box-Muller of seed,
+    call, utterance, sample) where generator.py:171 calls torch.randn_like.  With f0 = 0 everywhere the sines vanish and
+    atanh(s) - bias = (0.1 / 3) sum_h w_h z_h: mean, variance, kurtosis, independence along time / across utterances / across
+    calls, and repeatability for a given (seed, call)."""
+    from oracle import hift as ohift
+    w = ohift.fold_weight_norm(hift_sd)
+    lw, lb = w["m_source.l_linear.weight"].double().flatten(), float(w["m_source.l_linear.bias"])
+    B, T = 2, 150
+    f0 = torch.zeros(B, T)
+    phase = torch.zeros(B, 9)
+    s = eng.hift_source_seeded(f0, phase, 1234, 0).double().cpu().squeeze(1)
+    assert torch.equal(eng.hift_source_seeded(f0, phase, 1234, 0).double().cpu().squeeze(1), s)          # repeatable
+    s_call = eng.hift_source_seeded(f0, phase, 1234, 1).double().cpu().squeeze(1)
+    s_seed = eng.hift_source_seeded(f0, phase, 1235, 0).double().cpu().squeeze(1)
+    sigma = (0.1 / 3.0) * float(lw.pow(2).sum().sqrt())
+    z = (torch.atanh(s) - lb) / sigma
+    n = z.numel()
+    assert abs(float(z.mean())) < 5.0 / n ** 0.5
+    assert abs(float(z.var()) - 1.0) < 0.01
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.05 and abs(float((z ** 3).mean())) < 0.03      # (z is a sum of 9 weighted normals: normal)
+    corr = lambda a, b: float(((a - a.mean()) * (b - b.mean())).mean() / (a.std() * b.std()))
+    assert abs(corr(z[:, 1:].flatten(), z[:, :-1].flatten())) < 0.01             # along time
+    assert abs(corr(z[0], z[1])) < 0.01                                          # across utterances
+    for other in (s_call, s_seed):
+        zo = (torch.atanh(other) - lb) / sigma
+        assert abs(corr(z.flatten(), zo.flatten())) < 0.01 and not torch.equal(other, s)
+    # tails: P(|z| > 3) = 0.0027
+    assert abs(float((z.abs() > 3).double().mean()) - 0.0027) < 0.0006
+
+
 def test_hift_decode_golden(eng):
     g = load_golden("G5_hift")
     wav = eng.hift_decode(g["mel"], g["s"])

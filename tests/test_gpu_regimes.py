@@ -61,3 +61,29 @@ def test_throughput_is_monotone_and_every_regime_matches_the_oracle(tts_sd, nois
             best = max(best, rate[B])
     finally:
         eng.close()
+
+
+def test_forced_row_tile_at_two_utterances_matches_the_oracle(tts_sd, noise, monkeypatch):
+    """JV_ROWGEMM_RT (the debugging override tools/regime_sweep.py uses) forces the row-owning kernels at a row count that would
+    take the split-K tiles.  The two regimes hand the next block's LayerNorm on in different formats (fp32 rows from the
+    split-K tail, fp16 planes into the row-owning blocks): flow.hip keeps them mutually exclusive, and a forced tile height at
+    2 utterances must give the oracle's answer (round 3: NaN, and the sweep recorded it as 'not run')."""
+    from jyutvoice_amd.engine import JV_MODEL_TTS, Engine
+    from oracle import flow as oflow
+    g = torch.Generator().manual_seed(99)
+    Bn = 2
+    mu, spks = torch.randn(Bn, 80, T, generator=g), torch.randn(Bn, 80, generator=g)
+    want = oflow.cfm_solve(tts_sd, noise, mu[:1], torch.ones(1, 1, T), spks[:1], torch.zeros(1, 80, T), N_STEPS, 1.0)
+    for rt in ("2", "3"):
+        monkeypatch.setenv("JV_ROWGEMM_RT", rt)
+        eng = Engine("cuda:0", max_batch=Bn, max_frames=T + 4, max_tokens=32)
+        try:
+            eng.load_state_dict(JV_MODEL_TTS, tts_sd)
+            eng.load_noise(noise)
+            mel = eng.cfm_solve(mu.cuda(), None, spks.cuda(), torch.zeros(Bn, 80, T, device="cuda"), N_STEPS, 1.0)
+            torch.cuda.synchronize()
+            assert torch.isfinite(mel).all(), rt
+            err = float((mel[:1].cpu() - want).abs().max())
+            assert err <= 1e-3, (rt, err)
+        finally:
+            eng.close()
