@@ -617,6 +617,11 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   // ================================ phase C: q | k | v of the next block (rowgemm_wa_kernel's loop) ================================
   if constexpr (QKV) {
     waited = true;
+    // Phase C has no workgroup barrier: six independent 256-column chunks, each 8 steps of MFMAs and then a per-wave epilogue.
+    // A SIMD hosts waves w and w + 4 and its arbiter serves the OLDER wave first (tools/probes/wave_prio.hip: of two waves
+    // that start a run of independent MFMAs together, wave w finishes at the single-wave rate and wave w + 4 runs in what
+    // is left), so the pair drifts out of phase by itself -- one wave's epilogue under the other's MFMAs -- and an explicit
+    // s_setprio for waves 0..3 changed nothing (121.1 against 121.0 us per launch, same box).
     // (two patches per wave, alternating over the row groups: group mt + 1 is written while group mt's rows are still
     // being read back -- with one patch every group was an LDS write -> read round trip in series)
     float* const ws0 = slab + wave * (NPATCH * 16 * 36);
