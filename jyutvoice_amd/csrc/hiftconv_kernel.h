@@ -87,12 +87,12 @@ __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftconv_kernel(const H
   unsigned char* const img = reinterpret_cast<unsigned char*>(rowinfo) + R * 8;            // [NCH][2][WRP][64 B]
   float* const patch = reinterpret_cast<float*>(img + NCH * CS) + wave * (16 * 36);
 
-  // ---- W: fragment order, [plane][C / 16 blocks][KS][64 lanes][8 halves]; this wave's column blocks are 2 cp + nt ----
+  // ---- W: fragment order, [plane][KS][C / 16 blocks][64 lanes][8 halves] (k-step major); this wave's column blocks are 2 cp + nt ----
   const unsigned short* wp[2][2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) wp[nt][pl] = p.Wf + (long)pl * p.wf_plane + ((long)(2 * cp + nt) * KS) * 512 + lane * 8;
+    for (int pl = 0; pl < 2; ++pl) wp[nt][pl] = p.Wf + (long)pl * p.wf_plane + (long)(2 * cp + nt) * 512 + lane * 8;
   int wk = 0;
   rg_u32x4 bq[2][2][2];
 #pragma unroll
@@ -108,8 +108,9 @@ __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftconv_kernel(const H
   auto landed_w = [](rg_u32x4& b00, rg_u32x4& b01, rg_u32x4& b10, rg_u32x4& b11) {
     asm volatile("" : "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11)::"memory");
   };
-  auto advance_w = [&]() {      // + 1 KB (512 halves) per step; past the end: back to the first step (weights that exist)
-    const long d = ++wk == KS ? 512L - 512L * KS : 512L;
+  auto advance_w = [&]() {      // + C / 16 blocks x 1 KB (512 halves) per step; past the end: back to the first step (weights that exist)
+    constexpr long WSTEP = 512L * (C / 16);
+    const long d = ++wk == KS ? WSTEP - WSTEP * KS : WSTEP;
     if (wk == KS) wk = 0;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)

@@ -26,7 +26,11 @@
 // JV_TUNING=1 python -m jyutvoice_amd.build --force (tools/gemm_bench.py documents the switches).
 #ifdef JV_TUNING
 #define JV_ABLATE(p, bit) (((p).ablate & (bit)) != 0)
+#ifdef JV_NO_STAMPS      // (a tuning build without the in-kernel stamps: ablation switches only)
+#define JV_STAMP(p) (false)
+#else
 #define JV_STAMP(p) ((p).stamps != nullptr)
+#endif
 #else
 #define JV_ABLATE(p, bit) (false)
 #define JV_STAMP(p) (false)
@@ -221,8 +225,9 @@ struct SplitKReduceArgs {
   const float *ln2_g, *ln2_b; float* out2;              // optional: LayerNorm_256(out row) -> out2 [rows, 256]
 };
 int splitk_reduce_rows(const SplitKReduceArgs& a, hipStream_t st);
-// fp16 planes [2][N][ldw] (row n = output column n, K-contiguous) -> fragment order [2][N/16][K/32][64 lanes][8 halves]: lane
-// l of a v_mfma_f32_16x16x32_f16 B operand holds row 16 nb + (l & 15), k = 32 ks + 8 (l >> 4) ... + 8 (rowgemm.hip)
+// fp16 planes [2][N][ldw] (row n = output column n, K-contiguous) -> fragment order [2][K/32][N/16][64 lanes][8 halves] (k-step major: the
+// column blocks a workgroup loads in one step are contiguous): lane l of a v_mfma_f32_16x16x32_f16 B operand holds row
+// 16 nb + (l & 15), k = 32 ks + 8 (l >> 4) ... + 8 (rowgemm.hip)
 int pack_wfrag(const unsigned short* w2, long w2_plane, int ldw, int N, int K, unsigned short* wf, long wf_plane, hipStream_t st);
 int layernorm256_planes(const float* x, unsigned short* out2, long plane, float scale, const float* g, const float* b, float eps,
                         long rows, hipStream_t st);

@@ -6,19 +6,19 @@ namespace jv {
 int rowgemm_tile(int M);      // rowgemm.hip
 
 namespace {
-template <int RT, bool QKV>
+template <int RT, bool QKV, bool STAG>
 int rb_launch(const RowBlockArgs& a, hipStream_t st) {
   static bool raised[64] = {};
   int dev = 0;
   JV_HIP(hipGetDevice(&dev));
   if (!raised[dev & 63]) {
-    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowblock_kernel<RT, QKV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowblock_kernel<RT, QKV, STAG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                rb_lds_bytes<RT>()));
     raised[dev & 63] = true;
   }
   const bool prof = prof_on();
   if (prof) prof_begin(st);
-  hipLaunchKernelGGL((rowblock_kernel<RT, QKV>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rb_lds_bytes<RT>(), st, a);
+  hipLaunchKernelGGL((rowblock_kernel<RT, QKV, STAG>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rb_lds_bytes<RT>(), st, a);
   if (prof) {
     static const std::string name_plain = std::string("rowblock_h3<") + std::to_string(16 * RT) + "x256" + (QKV ? ",qkv>" : ">");
     static const std::string name_ln = std::string("rowblock_h3<") + std::to_string(16 * RT) + "x256,ln>";
@@ -34,9 +34,17 @@ int rb_launch(const RowBlockArgs& a, hipStream_t st) {
   return JV_OK;
 }
 
+// JV_NO_FF_STAGGER=1: the feed-forward with every wave in the same phase (the schedule before round 4; same results, for A/B runs)
+bool ff_stagger() {
+  static const bool off = getenv("JV_NO_FF_STAGGER") != nullptr;
+  const char* d = dyn_env("JV_NO_FF_STAGGER");
+  return !(off || (d && d[0] == '1'));
+}
+
 template <int RT>
 int rb_launch1(const RowBlockArgs& a, bool qkv, hipStream_t st) {
-  return qkv ? rb_launch<RT, true>(a, st) : rb_launch<RT, false>(a, st);
+  if (ff_stagger()) return qkv ? rb_launch<RT, true, true>(a, st) : rb_launch<RT, false, true>(a, st);
+  return qkv ? rb_launch<RT, true, false>(a, st) : rb_launch<RT, false, false>(a, st);
 }
 }  // namespace
 
@@ -61,6 +69,7 @@ int rowblock(const RowBlockArgs& a, bool qkv, hipStream_t st) {
   RowBlockArgs b = a;      // the reciprocals of the (power-of-two) scales, for the kernel
   b.inv_a_scale_o = 1.0f / a.a_scale_o; b.inv_a_scale1 = 1.0f / a.a_scale1; b.inv_h_scale = 1.0f / a.h_scale;
   b.inv_a_scale_q = qkv ? 1.0f / a.a_scale_q : 0.f;
+  if (const char* ab = tuning_env("JV_RB_ABLATE")) b.ablate = atoi(ab);
   switch (rt) {
     case 2: return rb_launch1<2>(b, qkv, st);
     case 3: return rb_launch1<3>(b, qkv, st);

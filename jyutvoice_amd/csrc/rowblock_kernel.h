@@ -75,6 +75,9 @@ struct RowBlockArgs {
   long ln_out_plane;
   long alg_rows;
   unsigned long long* stamps;      // tuning aid (JV_RB_STAMPS, tuning builds): [workgroup][48] s_memtime at the phase boundaries
+  // tuning aid (JV_RB_ABLATE, tuning builds; results are wrong by design): 1 GELU pass without its arithmetic, 2 no GELU pass at all,
+  // 4 phase C without global stores, 8 phase C without chunk epilogues, 16 residual epilogues without their row passes
+  int ablate;
 };
 
 template <int RT> constexpr int rb_lds_bytes() { return 16 * rgw_stage_bytes<RT>(); }
@@ -82,7 +85,7 @@ template <int RT> constexpr int rb_lds_bytes() { return 16 * rgw_stage_bytes<RT>
 // element (row, col) of the swizzled slab, in floats
 __device__ __forceinline__ int rb_slab(int row, int col) { return row * 256 + (col ^ (((row >> 2) & 3) << 4)); }
 
-template <int RT, bool QKV>
+template <int RT, bool QKV, bool STAG>
 __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rg_lds[];
   constexpr int R = 16 * RT;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   constexpr int NWL = 4;
   constexpr int KSA = 16, KS = 8, NCH = 4, NCQ = 6;
   constexpr int H_OFF = KS * STAGE;
-  constexpr int NSEG = QKV ? 2 + 2 * NCH + NCQ : 2 + 2 * NCH;
+  constexpr int NQUAD = QKV ? 4 + 4 * NCH + 2 * NCQ : 4 + 4 * NCH;      // 4-step runs of weight fragments (the walker below)
   constexpr int NRW = 2 * RT;                    // rows per wave in the row passes
   constexpr float LN_EPS = 1e-5f;                // nn.LayerNorm's default (transformer.py:355-443 builds its norms with it)
   constexpr long LDH = 256, LDQ = 512, LDKV = 1024;
@@ -125,8 +128,8 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   float* const slab = reinterpret_cast<float*>(hreg);
 
   // ---- L2 warm-up of the weights (rowgemm_kernel): the workgroups that share an XCD touch every 128-byte line of a matrix
-  // once.  Wo and W1 at kernel start; W2 while phase A's epilogue runs; Wqkv at the last GELU pass -- a matrix touched a
-  // hundred microseconds ahead would be gone from a 4 MB L2 by the time its phase starts.
+  // once.  Wo at kernel start; W1 in the middle of phase A; W2 while phase A's epilogue runs; Wqkv at the last GELU pass -- a
+  // matrix touched a hundred microseconds ahead would be gone from a 4 MB L2 by the time its phase starts.
   const int wgrp = blockIdx.x >> 3, wngrp = (gridDim.x + 7) >> 3;
   auto warm_lines = [&](const unsigned short* base, long plane_halves, long lines_per_plane, int round) -> float {
     const long per = (2 * lines_per_plane + wngrp - 1) / wngrp;
@@ -143,8 +146,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
     return v;
   };
   float warm = warm_lines(p.Wof, p.wof_plane, 2048, 0);      // 256 x 512 halves = 256 KB per plane
-  float warm1 = warm_lines(p.W1f, p.w1f_plane, 4096, 0);     // 1024 x 256 halves = 512 KB per plane
-  float warm2 = 0.f, warm3 = 0.f;
+  float warm1 = 0.f, warm2 = 0.f, warm3 = 0.f;
 
   // Per-row facts of the tracking (mask, slot, the slots' current maxima): lane j < NRW loads those of the wave's row j and
   // the row passes broadcast them with v_readlane.  Loaded HERE, at kernel start, where the dependent chain (row -> slot ->
@@ -191,30 +193,50 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
     for (int i = 0; i < PPW; ++i) cur[i] += 32;
   };
 
-  // ---- W: the segment walker.  Fragment (nt, pl) of step j of a segment sits at
-  //   base + pl * plane + (((blk0 + 2 wave + nt) * KSm + k0 + j) * 64 + lane) * 8 halves
+  // ---- W: the walker.  The launch's weight fragments are a sequence of QUADS, runs of four 32-deep steps inside one matrix:
+  // Wo k 0..15 (4 quads), then the feed-forward's 16 (W1[chunk] k 0..7 = 2 quads, W2[k-steps of the chunk] = 2 quads, per hidden
+  // chunk), then the six 256-column chunks of Wqkv (2 quads each).  Fragment (nt, pl) of step j of a quad sits at
+  //   base + pl * plane + (((k0 + j) * NBm + blk0 + 2 wave + nt) * 64 + lane) * 8 halves      (k-step major, NBm = the matrix's N / 16)
+  // STAG: waves 0..3 walk the feed-forward's quads in THEIR order of use (the staggered schedule below):
+  //   W1[0] | W2[c] first half, W1[c + 1], W2[c] second half (c = 0..2) | W2[3]
+  const bool hx = STAG && wave < 4;      // wave-uniform: the leading half of the workgroup
   const unsigned short* wp[2][2];
-  int wseg = 0, wj = 0;
-  auto seg_ptrs = [&](const int seg) {      // wave-uniform
+  int wq = 0, wj = 0, wstep = 16 * 512;      // wstep: halves from one k-step's fragments to the next's = NBm x 512
+  auto quad_ptrs = [&](const int q) {      // wave-uniform
     const unsigned short* base;
     long plane;
-    int blk0, ksm, k0;
-    if (seg < 2) {
-      base = p.Wof; plane = p.wof_plane; blk0 = 0; ksm = KSA; k0 = 8 * seg;
-    } else if (seg < 2 + 2 * NCH) {
-      const int c = (seg - 2) >> 1;
-      if (((seg - 2) & 1) == 0) { base = p.W1f; plane = p.w1f_plane; blk0 = 16 * c; ksm = 8; k0 = 0; }
-      else { base = p.W2f; plane = p.w2f_plane; blk0 = 0; ksm = 32; k0 = 8 * c; }
+    int blk0, nbm, k0;
+    if (q < 4) {
+      base = p.Wof; plane = p.wof_plane; blk0 = 0; nbm = 16; k0 = 4 * q;
+    } else if (q < 4 + 4 * NCH) {
+      const int f = q - 4;
+      int c = f >> 2, h = f & 1;
+      bool first = (f & 2) == 0;      // W1 (the chunk's first linear) or W2
+      if (hx) {
+        if (f < 2) { c = 0; first = true; h = f; }
+        else if (f >= 4 * NCH - 2) { c = NCH - 1; first = false; h = f - (4 * NCH - 2); }
+        else {
+          const int g = f - 2, r = g & 3;
+          c = g >> 2;
+          if (r == 0) { first = false; h = 0; }
+          else if (r == 3) { first = false; h = 1; }
+          else { first = true; c += 1; h = r - 1; }
+        }
+      }
+      if (first) { base = p.W1f; plane = p.w1f_plane; blk0 = 16 * c; nbm = 16 * NCH; k0 = 4 * h; }
+      else { base = p.W2f; plane = p.w2f_plane; blk0 = 0; nbm = 16; k0 = 8 * c + 4 * h; }
     } else {
-      base = p.Wqf; plane = p.wqf_plane; blk0 = 16 * (seg - 2 - 2 * NCH); ksm = 8; k0 = 0;
+      const int g = q - 4 - 4 * NCH;
+      base = p.Wqf; plane = p.wqf_plane; blk0 = 16 * (g >> 1); nbm = 16 * NCQ; k0 = 4 * (g & 1);
     }
+    wstep = nbm * 512;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
-        wp[nt][pl] = base + (long)pl * plane + ((long)(blk0 + 2 * wave + nt) * ksm + k0) * 512 + lane * 8;
+        wp[nt][pl] = base + (long)pl * plane + ((long)k0 * nbm + blk0 + 2 * wave + nt) * 512 + lane * 8;
   };
-  seg_ptrs(0);
+  quad_ptrs(0);
   rg_u32x4 bq[2][2][2];
 #pragma unroll
   for (int i = 0; i < 8; ++i) bq[i >> 2][(i >> 1) & 1][i & 1] = rg_u32x4{0u, 0u, 0u, 0u};
@@ -230,15 +252,15 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
     asm volatile("" : "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11)::"memory");
   };
   auto advance_w = [&]() {
-    if (++wj == 8) {
+    if (++wj == 4) {
       wj = 0;
-      if (++wseg == NSEG) wseg = 0;      // past the end: wrap around to weights that exist
-      seg_ptrs(wseg);
+      if (++wq == NQUAD) wq = 0;      // past the end: wrap around to weights that exist
+      quad_ptrs(wq);
     } else {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) wp[nt][pl] += 512;
+        for (int pl = 0; pl < 2; ++pl) wp[nt][pl] += wstep;
     }
   };
 
@@ -287,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
   // A warm-up value is "used" (an empty asm) where the wait costs nothing and is dead from then on.  Kept alive to the end
   // of the kernel it crossed the feed-forward loop -- in scratch: the compiler spilled it right behind the load, i.e. put an
   // s_waitcnt vmcnt(0) on a load that is an L2 miss BY DESIGN in front of phase A's epilogue (6 k cycles in the stamps).
-  asm volatile("" ::"v"(warm), "v"(warm1));
+  asm volatile("" ::"v"(warm));
   rg_barrier();
   stamp();      // 1: prologue done
   read_a(std::integral_constant<int, 0>{}, hreg);
@@ -345,6 +367,10 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
     };
 #pragma unroll 1
     for (int ks = 0; ks < KSA; ks += 2) {
+      // W1 is touched HERE, half a phase (~6 us) ahead of its first fragment loads: touched at kernel start it had left the
+      // L2 again by then -- 7.5 MB of attention planes and residual rows per XCD pass through in phase A -- and the stamps
+      // read 5.9 k cycles between the end of this loop and the epilogue's first instruction, the wait for those fragments
+      if (ks == KSA / 2) warm1 = warm_lines(p.W1f, p.w1f_plane, 4096, 0);     // 1024 x 256 halves = 512 KB per plane
       stepA(std::integral_constant<int, 0>{});
       stepA(std::integral_constant<int, 1>{});
     }
@@ -472,9 +498,9 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
     rg_lds_barrier();
     xstamp();      // 20: slab written
     cs4 = cs4 * p.inv_a_scale_o;      // (first use of a loaded value: HERE, behind the barriers that hide the loads' ~2 k cycles, not in front of them)
-    row_pass(cs4, b4, rpre, facts_h, p.h, LDH, p.amax_h, true, gg, bb, p.a_scale1, nullptr);
+    if (!JV_ABLATE(p, 16)) row_pass(cs4, b4, rpre, facts_h, p.h, LDH, p.amax_h, true, gg, bb, p.a_scale1, nullptr);
     xstamp();      // 21: row pass done (this wave)
-    asm volatile("" ::"v"(warm2));      // (issued a whole row pass ago)
+    asm volatile("" ::"v"(warm2), "v"(warm1));      // (issued a whole row pass ago / in the middle of phase A)
     rg_lds_barrier();      // X is complete, the slab has been read: the upper half is free for H
   }
   stamp();      // 3: epilogue A done
@@ -513,74 +539,134 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) acc2[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
   const float inv1 = p.inv_a_scale1;
-#pragma unroll 1
-  for (int c = 0; c < NCH; ++c) {
-    // ---- the hidden chunk ----
+  // the pieces of a hidden chunk: the first linear's per-column constants, its 8 steps over X into acc1, the GELU pass that
+  // turns acc1 into stage `wave` of the hidden image H, and a run of 4 steps of the second linear over H into acc2
+  float csl[2], bl[2];
+  auto load_cs = [&](const int c) {
     const int hc0 = c * 256 + wave * 32 + r16;
-    float csl[2], bl[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       csl[nt] = p.cs1[hc0 + 16 * nt] * inv1;
       bl[nt] = p.b1 ? p.b1[hc0 + 16 * nt] : 0.f;
     }
+  };
+  auto p1_run = [&](const bool have) {      // have: stage 0 of X was requested by the step before
 #pragma unroll
     for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int ks = 0; ks < KS; ks += 2) {
-      step(std::integral_constant<int, 0>{}, acc1, rg_lds + ks * STAGE, rg_lds + (ks + 1) * STAGE, ks > 0 || c > 0);
+      step(std::integral_constant<int, 0>{}, acc1, rg_lds + ks * STAGE, rg_lds + (ks + 1) * STAGE, ks > 0 || have);
       step(std::integral_constant<int, 1>{}, acc1, rg_lds + (ks + 1) * STAGE, ks + 2 < KS ? rg_lds + (ks + 2) * STAGE : nullptr, true);
     }
-    stamp();      // 4 + 3 c: phase 1 done
-    if constexpr (QKV) {
-      // q|k|v's weights are touched HERE, ~30 us ahead of phase C: younger than every W load in flight and followed by a
-      // GELU pass without a counted wait, so they stall nothing (in phase B's epilogue they came too late: its first
-      // fragment loads, issued two steps earlier, were cold misses the epilogue then sat waiting for)
-      if (c == NCH - 1) warm3 = warm_lines(p.Wqf, p.wqf_plane, 6144, 0);      // 1536 x 256 halves = 768 KB per plane
+  };
+  auto p2_run = [&](const int k0, const int n, const bool have, const unsigned char* const after) {      // stages k0 .. k0 + n - 1 of H
+#pragma unroll 1
+    for (int ks = k0; ks < k0 + n; ks += 2) {
+      step(std::integral_constant<int, 0>{}, acc2, hreg + ks * STAGE, hreg + (ks + 1) * STAGE, ks > k0 || have);
+      step(std::integral_constant<int, 1>{}, acc2, hreg + (ks + 1) * STAGE, ks + 2 < k0 + n ? hreg + (ks + 2) * STAGE : after, true);
     }
-    // ---- GELU -> planes, into stage `wave` of H (rowffn_kernel) ----
-    if (c > 0) rg_lds_barrier();      // every wave is done reading the previous chunk's H
-    {
-      // A lane holds ONE hidden column (k) of rows 4 kq + e: written as it stands that is 2-byte LDS stores (80 per lane and
-      // chunk, two lanes per bank word).  Neighbouring lanes (columns k, k + 1) trade one row of each pair instead -- the
-      // even lane takes row e of both columns, the odd lane row e + 1 -- and store whole dwords: half the LDS instructions.
-      unsigned char* const hs = hreg + wave * STAGE;
-      const int key = (kq & 1) << 1;
-      const int odd = r16 & 1;
-      // v_perm_b32 selectors (bytes of {hi operand, lo operand} = {partner, mine}): even: (mine.lo16 | partner.lo16 << 16),
-      // odd: (partner.hi16 | mine.hi16 << 16)
-      const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+  };
+  auto gelu_pass = [&]() {      // GELU -> planes, into stage `wave` of H (rowffn_kernel)
+    if (JV_ABLATE(p, 2)) return;
+    // A lane holds ONE hidden column (k) of rows 4 kq + e: written as it stands that is 2-byte LDS stores (80 per lane and
+    // chunk, two lanes per bank word).  Neighbouring lanes (columns k, k + 1) trade one row of each pair instead -- the
+    // even lane takes row e of both columns, the odd lane row e + 1 -- and store whole dwords: half the LDS instructions.
+    unsigned char* const hs = hreg + wave * STAGE;
+    const int key = (kq & 1) << 1;
+    const int odd = r16 & 1;
+    // v_perm_b32 selectors (bytes of {hi operand, lo operand} = {partner, mine}): even: (mine.lo16 | partner.lo16 << 16),
+    // odd: (partner.hi16 | mine.hi16 << 16)
+    const unsigned sel = odd ? 0x03020706u : 0x05040100u;
 #pragma unroll
-      for (int mt = 0; mt < RT; ++mt)
+    for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const int slot = (2 * nt + (r16 >> 3)) ^ key;
-          float g4[4];
+      for (int nt = 0; nt < 2; ++nt) {
+        const int slot = (2 * nt + (r16 >> 3)) ^ key;
+        float g4[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) g4[e] = gelu_erf(acc1[mt][nt][e] * csl[nt] + bl[nt]) * p.h_scale;
+        for (int e = 0; e < 4; ++e) g4[e] = JV_ABLATE(p, 1) ? acc1[mt][nt][e] : gelu_erf(acc1[mt][nt][e] * csl[nt] + bl[nt]) * p.h_scale;
 #pragma unroll
-          for (int e = 0; e < 4; e += 2) {
-            const Split2 sp = split2h_pair(g4[e], g4[e + 1]);      // (row e | row e + 1 << 16) of this lane's column
-            const unsigned ph = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sp.h, 0xB1, 0xf, 0xf, true);      // the neighbour's
-            const unsigned pl = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sp.l, 0xB1, 0xf, 0xf, true);
-            const unsigned wh = __builtin_amdgcn_perm(ph, sp.h, sel), wl = __builtin_amdgcn_perm(pl, sp.l, sel);
-            const int row = mt * 16 + kq * 4 + e + odd;
-            unsigned char* d = hs + row * 64 + (slot << 4) + (r16 & 6) * 2;
-            *reinterpret_cast<unsigned*>(d) = wh;
-            *reinterpret_cast<unsigned*>(d + A_PLANE) = wl;
+        for (int e = 0; e < 4; e += 2) {
+          const Split2 sp = JV_ABLATE(p, 1) ? Split2{__float_as_uint(g4[e]), __float_as_uint(g4[e + 1])}
+                                            : split2h_pair(g4[e], g4[e + 1]);      // (row e | row e + 1 << 16) of this lane's column
+          const unsigned ph = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sp.h, 0xB1, 0xf, 0xf, true);      // the neighbour's
+          const unsigned pl = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sp.l, 0xB1, 0xf, 0xf, true);
+          const unsigned wh = __builtin_amdgcn_perm(ph, sp.h, sel), wl = __builtin_amdgcn_perm(pl, sp.l, sel);
+          const int row = mt * 16 + kq * 4 + e + odd;
+          unsigned char* d = hs + row * 64 + (slot << 4) + (r16 & 6) * 2;
+          *reinterpret_cast<unsigned*>(d) = wh;
+          *reinterpret_cast<unsigned*>(d + A_PLANE) = wl;
+        }
+      }
+  };
+  // q|k|v's weights are touched ~30 us ahead of phase C: younger than every W load in flight and followed by a GELU pass
+  // without a counted wait, so they stall nothing (in phase B's epilogue they came too late: its first fragment loads,
+  // issued two steps earlier, were cold misses the epilogue then sat waiting for)
+  auto warm_q = [&]() {
+    if constexpr (QKV) warm3 = warm_lines(p.Wqf, p.wqf_plane, 6144, 0);      // 1536 x 256 halves = 768 KB per plane
+  };
+  if constexpr (!STAG) {
+    // ---- every wave in the same phase: first linear -> GELU -> second linear, chunk by chunk ----
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+      load_cs(c);
+      p1_run(c > 0);
+      stamp();      // 4 + 3 c: phase 1 done
+      if (c == NCH - 1) warm_q();
+      if (c > 0) rg_lds_barrier();      // every wave is done reading the previous chunk's H
+      gelu_pass();
+      rg_lds_barrier();      // H complete
+      stamp();      // 5 + 3 c: GELU done
+      p2_run(0, KS, false, c + 1 < NCH ? rg_lds : nullptr);
+      stamp();      // 6 + 3 c: phase 2 done
+    }
+  } else {
+    // ---- STAGGERED: the two waves of a SIMD (w and w + 4) never run the GELU pass together.  With every wave in the same
+    // phase the matrix pipe idles through each GELU pass (4 x ~6 k cycles a launch, MI355X_MICROARCH.md "Two waves per SIMD"
+    // item 9); here waves 0..3 (X, which produce stages 0..3 of H) run half a chunk AHEAD of waves 4..7 (Y, stages 4..7), so one
+    // half's GELU pass runs under the other half's MFMAs.  The second linear must take H's stages in ascending order (the sum's
+    // K order is the unfused kernels'), so X fills the time until Y's stages exist with the NEXT chunk's first linear:
+    //           X (waves 0..3)                          Y (waves 4..7)
+    //   start   first(0), GELU(0)                      first(0)
+    //   I1(c)   second(c) k 0..3, first(c + 1)         GELU(c)                                    | barrier: stages 4..7 of H(c) exist
+    //   I2(c)   second(c) k 4..7                       second(c) k 0..3                           | barrier: stages 0..3 of H(c) are free
+    //   I3(c)   GELU(c + 1)                            second(c) k 4..7, first(c + 1)             | barrier: stages 0..3 of H(c + 1) exist
+    // Every barrier separates a write of H stages from their reads or their reads from the next write (three per chunk
+    // instead of two).  The weight walker above hands each half its fragments in its own order of use.
+    // (written as ONE loop body whose two role phases swap the halves, so that the GELU pass and the step bodies exist once)
+    load_cs(0);
+    p1_run(false);      // both halves: first(0); X, the older wave of each SIMD, wins the matrix pipe and gets ahead by itself
+    stamp();      // 4
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+      const bool more = c + 1 < NCH;
+#pragma unroll 1
+      for (int ph = 0; ph < 2; ++ph) {
+        // ph 0 = I3(c - 1): X GELU(c)                    | Y second(c - 1) k 4..7, first(c)    (c = 0: Y has nothing left to do)
+        // ph 1 = I1(c):     X second(c) k 0..3, first(c + 1) | Y GELU(c)
+        if (hx == (ph == 0)) {
+          if (c == NCH - 1) warm_q();
+          gelu_pass();
+        } else {
+          const bool do_p2 = hx || c > 0;
+          const bool do_p1 = hx ? more : c > 0;
+          if (do_p2) p2_run(hx ? 0 : 4, 4, false, do_p1 ? rg_lds : nullptr);
+          if (do_p1) {
+            load_cs(hx ? c + 1 : c);
+            p1_run(true);
           }
         }
+        rg_lds_barrier();
+        stamp();      // 5 + 3 c, 6 + 3 c
+      }
+      // I2(c): X second(c) k 4..7 | Y second(c) k 0..3
+      p2_run(hx ? 4 : 0, 4, false, nullptr);
+      if (more) rg_lds_barrier();      // (the last one is the epilogue's)
+      stamp();      // 7 + 3 c
     }
-    rg_lds_barrier();      // H complete
-    stamp();      // 5 + 3 c: GELU done
-#pragma unroll 1
-    for (int ks = 0; ks < KS; ks += 2) {
-      step(std::integral_constant<int, 0>{}, acc2, hreg + ks * STAGE, hreg + (ks + 1) * STAGE, ks > 0);
-      step(std::integral_constant<int, 1>{}, acc2, hreg + (ks + 1) * STAGE,
-           ks + 2 < KS ? hreg + (ks + 2) * STAGE : (c + 1 < NCH ? rg_lds : nullptr), true);
-    }
-    stamp();      // 6 + 3 c: phase 2 done
+    if (!hx) p2_run(4, 4, false, nullptr);      // Y's last four steps
   }
   xstamp();      // B0: loop done
   rg_wait_vmcnt<2>();      // what the next step's middle needs (if there is one), ahead of the epilogue's own memory operations
@@ -607,8 +693,9 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
     rg_lds_barrier();
     xstamp();      // 24: slab written
     cs4 = cs4 * p.inv_h_scale;
-    row_pass(cs4, b4, rpre, facts_o, p.out, QKV ? LDH : p.ldo, p.amax_out, ln_b, gg, bb, ln_b ? p.a_scale_q : 1.f,
-             QKV ? nullptr : p.ln_out);      // (q|k|v follows only where out is the trunk itself)
+    if (!JV_ABLATE(p, 16))
+      row_pass(cs4, b4, rpre, facts_o, p.out, QKV ? LDH : p.ldo, p.amax_out, ln_b, gg, bb, ln_b ? p.a_scale_q : 1.f,
+               QKV ? nullptr : p.ln_out);      // (q|k|v follows only where out is the trunk itself)
     xstamp();      // 25: row pass done
     if constexpr (QKV) rg_lds_barrier();      // X is complete, the slab has been read: the patches go over it
   }
@@ -646,31 +733,52 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
       }
       // the chunk's epilogue, per wave, through its private 16 x 36-float patch (rowgemm_wa_kernel): q -> fp32 rows, k / v -> planes
       const int nw = c * 256 + wave * 32 + pc4;
-      rg_f32x4 cw = *reinterpret_cast<const rg_f32x4*>(p.csq + nw);
-      cw = cw * p.inv_a_scale_q;
       const float sc = c < 4 ? p.k_scale : p.v_scale;
+      if (JV_ABLATE(p, 8)) continue;
+      if (c < 2) {      // q: fp32 rows, 8 lanes x 16 B per row segment
+        rg_f32x4 cw = *reinterpret_cast<const rg_f32x4*>(p.csq + nw);
+        cw = cw * p.inv_a_scale_q;
 #pragma unroll
-      for (int mt = 0; mt < RT; ++mt) {
-        float* const ws = ws0 + (mt & (NPATCH - 1)) * (16 * 36);
+        for (int mt = 0; mt < RT; ++mt) {
+          float* const ws = ws0 + (mt & (NPATCH - 1)) * (16 * 36);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+          for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) ws[(kq * 4 + e) * 36 + nt * 16 + r16] = acc1[mt][nt][e];
+            for (int e = 0; e < 4; ++e) ws[(kq * 4 + e) * 36 + nt * 16 + r16] = acc1[mt][nt][e];
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-          const int trow = mt * 16 + ps * 8 + prow;
-          const long mrow = (long)m0 + trow;
-          rg_f32x4 v = *reinterpret_cast<const rg_f32x4*>(ws + (ps * 8 + prow) * 36 + pc4) * cw;
-          if (mrow >= p.M) continue;
-          if (c < 2) {
+          for (int ps = 0; ps < 2; ++ps) {
+            const int trow = mt * 16 + ps * 8 + prow;
+            const long mrow = (long)m0 + trow;
+            const rg_f32x4 v = *reinterpret_cast<const rg_f32x4*>(ws + (ps * 8 + prow) * 36 + pc4) * cw;
+            if (mrow >= p.M || JV_ABLATE(p, 4) && v[0] != 123.456f) continue;
             *(__attribute__((address_space(1))) rg_f32x4*)(p.q + mrow * LDQ + nw) = v;
-          } else {
-            const Split2 s0 = split2h_pair(v[0] * sc, v[1] * sc);
-            const Split2 s1 = split2h_pair(v[2] * sc, v[3] * sc);
-            unsigned short* o2 = p.kv2 + mrow * LDKV + (nw - 512);
-            *(__attribute__((address_space(1))) rg_u32x2*)(o2) = rg_u32x2{s0.h, s1.h};
-            *(__attribute__((address_space(1))) rg_u32x2*)(o2 + p.kv2_plane) = rg_u32x2{s0.l, s1.l};
           }
+        }
+      } else {
+        // k / v: fp16 planes.  A lane takes EIGHT columns of a row (4 lanes per row segment, 16 rows per pass): 16 bytes per
+        // plane and lane -- with four columns per lane the planes left as 8-byte stores, twice the store instructions, and
+        // the chunk epilogue is bound by store issue (MI355X_MICROARCH.md: 8-byte accesses run at 0.54 - 0.70 of the 16-byte rate)
+        const int prow16 = lane >> 2, pc8 = (lane & 3) * 8;
+        const int nw8 = c * 256 + wave * 32 + pc8;
+        rg_f32x4 cw0 = *reinterpret_cast<const rg_f32x4*>(p.csq + nw8), cw1 = *reinterpret_cast<const rg_f32x4*>(p.csq + nw8 + 4);
+        cw0 = cw0 * (p.inv_a_scale_q * sc);      // (powers of two: the same bits as scaling the product)
+        cw1 = cw1 * (p.inv_a_scale_q * sc);
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt) {
+          float* const ws = ws0 + (mt & (NPATCH - 1)) * (16 * 36);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ws[(kq * 4 + e) * 36 + nt * 16 + r16] = acc1[mt][nt][e];
+          const long mrow = (long)m0 + mt * 16 + prow16;
+          const rg_f32x4 v0 = *reinterpret_cast<const rg_f32x4*>(ws + prow16 * 36 + pc8) * cw0;
+          const rg_f32x4 v1 = *reinterpret_cast<const rg_f32x4*>(ws + prow16 * 36 + pc8 + 4) * cw1;
+          if (mrow >= p.M || JV_ABLATE(p, 4) && v0[0] != 123.456f) continue;
+          const Split2 s0 = split2h_pair(v0[0], v0[1]), s1 = split2h_pair(v0[2], v0[3]);
+          const Split2 s2 = split2h_pair(v1[0], v1[1]), s3 = split2h_pair(v1[2], v1[3]);
+          unsigned short* const o2 = p.kv2 + mrow * LDKV + (nw8 - 512);
+          *(__attribute__((address_space(1))) rg_u32x4*)(o2) = rg_u32x4{s0.h, s1.h, s2.h, s3.h};
+          *(__attribute__((address_space(1))) rg_u32x4*)(o2 + p.kv2_plane) = rg_u32x4{s0.l, s1.l, s2.l, s3.l};
         }
       }
       stamp();      // 18 + 2 c: chunk epilogue done

@@ -400,8 +400,8 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) wbase[nt][pl] = p.Wf + (long)pl * p.wf_plane + ((long)(wave * 2 + nt) * KSW) * 512 + lane * 8;
-  long woff = 0;       // halves: fragment step of the NEXT step to load, x 512
+    for (int pl = 0; pl < 2; ++pl) wbase[nt][pl] = p.Wf + (long)pl * p.wf_plane + (long)(wave * 2 + nt) * 512 + lane * 8;
+  long woff = 0;       // halves: fragment step of the NEXT step to load, x 16 column blocks x 512 (k-step major: pack_wfrag)
   int wj = 0, wc = 0;  // its tap and chunk
   rg_u32x4 bq[2][2][2];
 #pragma unroll
@@ -421,9 +421,9 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
     if (++wj == 3) {
       wj = 0;
       if (++wc == NCH) { wc = 0; woff = 0; }
-      else woff += (1L - 2L * NCH) * 512;
+      else woff += (1L - 2L * NCH) * (16 * 512);
     } else {
-      woff += (long)NCH * 512;
+      woff += (long)NCH * (16 * 512);
     }
   };
   // The weights start first: everything below (row slots -> measured bounds -> first A window) is a chain of dependent

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wd_kernel(const RowGemmArgs p)
 #pragma unroll
     for (int i = 0; i < PPW; ++i) cur[i] += wrap ? 32 - p.K : 32;
   };
-  // ---- W: fragment-ordered, [plane][N/16][KS][64 lanes][8 halves]; this wave's column blocks are c*16 + wave*2 + nt ----
+  // ---- W: fragment-ordered, [plane][KS][N/16][64 lanes][8 halves] (k-step major: pack_wfrag); this wave's column blocks are c*16 + wave*2 + nt ----
   // per-lane pointers of the four fragments (column block nt, plane pl) at (chunk 0, step 0); `woff` walks the (chunk,
   // k-step) sequence in halves.  (A scalar base with 32-bit lane offsets -- global_load_dwordx4 v, v_off, s[base] -- would
   // save the 64-bit adds, but from inline asm it faulted: the base reached the asm through v_readfirstlane, and a VMEM
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wd_kernel(const RowGemmArgs p)
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) wbase[nt][pl] = p.Wf + (long)pl * p.wf_plane + ((long)(wave * 2 + nt) * KS) * 512 + lane * 8;
+    for (int pl = 0; pl < 2; ++pl) wbase[nt][pl] = p.Wf + (long)pl * p.wf_plane + (long)(wave * 2 + nt) * 512 + lane * 8;
   long woff = 0;
   int wk = 0;
   // The register double buffer is loaded and waited for by hand (inline asm): left to the compiler, the wait in front of
@@ -532,15 +532,16 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wd_kernel(const RowGemmArgs p)
     asm volatile("" : "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11)::"memory");
   };
   int wc = 0;
-  auto advance_w = [&]() {      // + 1 KB (512 halves) per step, + 15 KS KB more at a chunk boundary, back to the start after the last chunk
+  const long wstep = 512L * 16 * NC;      // a k-step on: N / 16 column blocks x 1 KB (512 halves) per plane
+  auto advance_w = [&]() {      // (chunk wc, step wk) sits (wk N/16 + 16 wc) KB into a plane; back to the start after the last chunk
     const bool wrap = ++wk == KS;
     if (wrap) {
       wk = 0;
       const bool end = ++wc == NC;
       if (end) wc = 0;
-      woff += end ? 512L + 15L * KS * 512 - 16L * KS * 512 * NC : 512L + 15L * KS * 512;
+      woff += 16L * 512 - (KS - 1) * wstep - (end ? 16L * 512 * NC : 0L);
     } else {
-      woff += 512L;
+      woff += wstep;
     }
   };
 
@@ -909,8 +910,8 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wa_kernel(const RowGemmArgs p)
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) wbase[nt][pl] = p.Wf + (long)pl * p.wf_plane + ((long)(wave * 2 + nt) * KS) * 512 + lane * 8;
-  long woff = 16L * KS * 512 * c0;      // a chunk is 16 column blocks x KS steps x 1 KB per plane
+    for (int pl = 0; pl < 2; ++pl) wbase[nt][pl] = p.Wf + (long)pl * p.wf_plane + (long)(wave * 2 + nt) * 512 + lane * 8;
+  long woff = 16L * 512 * c0;      // (chunk c, step ks) sits (ks N/16 + 16 c) KB into a plane
   int wk = 0, wc = c0;
   rg_u32x4 bq[2][2][2];
 #pragma unroll
@@ -926,15 +927,16 @@ __global__ __launch_bounds__(512, 2) void rowgemm_wa_kernel(const RowGemmArgs p)
   auto landed_w = [](rg_u32x4& b00, rg_u32x4& b01, rg_u32x4& b10, rg_u32x4& b11) {
     asm volatile("" : "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11)::"memory");
   };
-  auto advance_w = [&]() {      // + 1 KB (512 halves) per step, + 15 KS KB more at a chunk boundary, back to this workgroup's first chunk after its last
+  const long wstep = 512L * (p.N >> 4);      // a k-step on: N / 16 column blocks x 1 KB per plane
+  auto advance_w = [&]() {      // back to this workgroup's first chunk after its last
     const bool wrap = ++wk == KS;
     if (wrap) {
       wk = 0;
       const bool end = ++wc == c1;
       if (end) wc = c0;
-      woff += end ? 512L + 15L * KS * 512 - 16L * KS * 512 * (c1 - c0) : 512L + 15L * KS * 512;
+      woff += 16L * 512 - (KS - 1) * wstep - (end ? 16L * 512 * (c1 - c0) : 0L);
     } else {
-      woff += 512L;
+      woff += wstep;
     }
   };
   load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -1162,8 +1164,8 @@ __global__ __launch_bounds__(512, 2) void rowffn_kernel(const RowFfnArgs p) {
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
-      w1base[nt][pl] = p.W1f + (long)pl * p.w1f_plane + ((long)(wave * 2 + nt) * 8) * 512 + lane * 8;
-      w2base[nt][pl] = p.W2f + (long)pl * p.w2f_plane + ((long)(wave * 2 + nt) * 32) * 512 + lane * 8;
+      w1base[nt][pl] = p.W1f + (long)pl * p.w1f_plane + (long)(wave * 2 + nt) * 512 + lane * 8;
+      w2base[nt][pl] = p.W2f + (long)pl * p.w2f_plane + (long)(wave * 2 + nt) * 512 + lane * 8;
     }
   long off1 = 0, off2 = 0;      // halves: where the NEXT step to load sits in W1f / W2f
   int wph = 0, wk = 0, wcc = 0; // its phase, k-step, chunk
@@ -1182,12 +1184,13 @@ __global__ __launch_bounds__(512, 2) void rowffn_kernel(const RowFfnArgs p) {
     asm volatile("" : "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11)::"memory");
   };
   auto advance_w = [&]() {
-    // W1f: block (16 c + 2 wave + nt), k-step ks -> ((16 c) 8 + ks) 512 halves past the base; W2f: k-step 8 c + ks
-    if (wph == 0) off1 += 512; else off2 += 512;
+    // k-step major fragments: W1f (64 column blocks): block 16 c + 2 wave + nt, k-step ks -> (64 ks + 16 c) 512 halves past the
+    // base; W2f (16 blocks): k-step 8 c + ks -> 16 (8 c + ks) 512
+    if (wph == 0) off1 += 64L * 512; else off2 += 16L * 512;
     if (++wk == KS) {
       wk = 0;
       if (wph == 0) {
-        off1 += 120L * 512;      // next chunk's blocks: + 16 blocks x 8 steps, less the 8 just walked
+        off1 += (16L - 8L * 64) * 512;      // next chunk's blocks: + 16 blocks, less the 8 steps just walked
         wph = 1;
       } else {
         wph = 0;

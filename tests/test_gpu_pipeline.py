@@ -374,6 +374,32 @@ def test_fused_block_equals_separate_launches(monkeypatch):
         assert torch.equal(f, s), float((f - s).abs().max())
 
 
+def test_ff_stagger_equals_lockstep(monkeypatch):
+    """rowblock_kernel's staggered feed-forward (waves 0..3 half a hidden chunk ahead of waves 4..7, so that one half's GELU
+    pass runs under the other half's MFMAs; three barriers per chunk, each half's weight fragments in its own order) against
+    the schedule with every wave in the same phase (JV_NO_FF_STAGGER=1): the same sums in the same K order -- the mels must
+    be equal bit for bit, at tile heights 5 (32 utterances), 2 (ragged 8: the q | k | v split regime, rowblock without phase C)
+    and 4 (ragged 20, last workgroup partly past the end)"""
+    import jyutvoice_amd
+    from jyutvoice_amd import synth
+    sd = synth.tts_state_dict(fixed_duration=1.5)
+    keys = ("x", "x_lengths", "lang", "tone", "word_pos", "syllable_pos", "spk_embed")
+    cases = [synth.batch(32, 150), synth.batch(8, 150, first_index=40, lengths=[150 - 11 * i for i in range(8)]),
+             synth.batch(20, 131, first_index=7, lengths=[131 - 3 * i for i in range(20)])]
+
+    def run():
+        tts, _ = jyutvoice_amd.build_default("cuda:0")
+        tts.load_state_dict(sd)
+        return [tts.synthesise(*[b[k] for k in keys], None, n_timesteps=2, batched=True)["mel"].cpu() for b in cases]
+
+    stag = run()
+    monkeypatch.setenv("JV_NO_FF_STAGGER", "1")
+    lock = run()
+    for a, b in zip(stag, lock):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), float((a - b).abs().max())
+
+
 def test_split_qkv_equals_fused_block(monkeypatch):
     """Mid-size batches (64 - 170 row tiles on 256 CUs): the next block's q | k | v leaves the fused launch -- phase B's
     epilogue writes the LayerNorm1 planes to HBM and rowgemm_wa_kernel runs with its six column chunks dealt over 3 or 6
