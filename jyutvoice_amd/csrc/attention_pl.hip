@@ -89,8 +89,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (NST == 2 ? 4 : 3)) void att
   }
   const int q0 = qt * 32 * NW + wave * 32;
   const int len = p.lens ? min(p.lens[b], p.L) : p.L;
-  const long rowbase = (long)p.G + (long)b * p.S;
-  const bool active = q0 < p.L;
+  // compact geometry (AttnArgs::uoff): the utterance owns len rows; what lies behind them is the next utterance
+  const long rowbase = p.uoff ? (long)p.uoff[b] : (long)p.G + (long)b * p.S;
+  const int Lq = p.uoff ? len : p.L;
+  if (qt * 32 * NW >= Lq) return;      // (the whole workgroup: nothing of it lies inside the utterance; uniform geometry: never)
+  const bool active = q0 < Lq;
 
   // Q planes: lane (query, half) holds d = 16 s + 8 half + j for k-step s, pre-scaled by log2(e) / 8 * q_scale
   u32x4 q[4][2];
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (NST == 2 ? 4 : 3)) void att
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
-      if (qi < p.L) {
+      if (qi < Lq) {
         t0 = *reinterpret_cast<const f32x4*>(src + 16 * s);
         t1 = *reinterpret_cast<const f32x4*>(src + 16 * s + 4);
       }
@@ -275,14 +278,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (NST == 2 ? 4 : 3)) void att
       const int pl = idx / (32 * NW * 8), rem = idx % (32 * NW * 8);
       const int qrow = rem >> 3, piece = rem & 7;
       const int qi = qt * 32 * NW + qrow;
-      if (qi < p.L) {
+      if (qi < Lq) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(so + (pl * 32 * NW + qrow) * 128 + ((piece ^ ((qrow >> 1) & 7)) << 4));
         *reinterpret_cast<u32x4*>(p.out2 + (long)pl * p.out2_plane + (rowbase + qi) * p.ldo + h * 64 + piece * 8) = v;
       }
     }
   } else {
     const int qi = q0 + r32;
-    if (active && qi < p.L) {
+    if (active && qi < Lq) {
       float* dst = p.out + (rowbase + qi) * p.ldo + h * 64 + 4 * half;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {

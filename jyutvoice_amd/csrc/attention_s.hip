@@ -179,8 +179,10 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
   const int b = blockIdx.x / (nqt * p.H);
   const int q0 = qt * AS_NW * QW + wave * QW;
   const int len = p.lens ? min(p.lens[b], p.L) : p.L;
-  const long rowbase = (long)p.G + (long)b * p.S;
-  const bool active = q0 < p.L;
+  // compact geometry (AttnArgs::uoff): the utterance owns len rows; what lies behind them is the next utterance
+  const long rowbase = p.uoff ? (long)p.uoff[b] : (long)p.G + (long)b * p.S;
+  const int Lq = p.uoff ? len : p.L;
+  const bool active = q0 < Lq;
 
   // ---- this wave's DMA pieces of a key tile (attention_pl.hip): piece pc = wave + 2 i -> operand pc >> 3, plane (pc >> 2) & 1,
   // 8-key group pc & 3; lane L lands on key 8 g + (L >> 3), slot L & 7
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
   f32x4 qraw[2][8];
   auto fetch_q = [&](const int t, f32x4 (&r)[8]) {
     const int qi = q0 + 32 * t + r32;
-    const float* qs = p.qkv + (rowbase + min(qi, p.L - 1)) * p.ld + h * 64 + 8 * half;      // (clamped: zeroed below)
+    const float* qs = p.qkv + (rowbase + max(min(qi, Lq - 1), 0)) * p.ld + h * 64 + 8 * half;      // (clamped: zeroed below)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       r[2 * s] = *(const __attribute__((address_space(1))) f32x4*)(qs + 16 * s);
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     if (t + 1 < QT) fetch_q(t + 1, qraw[(t + 1) & 1]);
-    const float live = (q0 + 32 * t + r32) < p.L ? qsc : 0.f;
+    const float live = (q0 + 32 * t + r32) < Lq ? qsc : 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const f32x4 t0 = qraw[t & 1][2 * s], t1 = qraw[t & 1][2 * s + 1];
@@ -317,14 +319,14 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
   const float vsc = p.v_scale;
   auto write_tile = [&](auto tc, unsigned char* const so) __attribute__((always_inline)) {
     constexpr int T = decltype(tc)::value;
-    (void)vsc, (void)l_run, (void)rowbase, (void)h;
+    (void)vsc, (void)l_run, (void)rowbase, (void)h, (void)Lq;
     // (everything below is invariant over the key loop this is called from: made opaque, or the compiler hoists ~70 address
     //  and predicate registers out of the loop and parks them in AGPRs -- the ones this kernel owns)
     int q0l = q0, lane = tid & 63;
     asm volatile("" : "+v"(q0l), "+v"(lane));
     const int r32 = lane & 31, half = lane >> 5;
     const int qbase = q0l + 32 * T;
-    if (qbase >= p.L) return;      // (wave-uniform)
+    if (qbase >= Lq) return;      // (wave-uniform)
     asm volatile("s_nop 15\n\ts_nop 15");      // the tile's last PV MFMA may have been issued one instruction ago
     const float l = l_run[T];
     const float inv = l > 0.f ? (1.0f / vsc) / l : 0.f;
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
         const int pl = it >> 2, qrow = (it & 3) * 8 + (lane >> 3), piece = lane & 7;
         const int qi = qbase + qrow;
         const u32x4 v = *reinterpret_cast<const u32x4*>(so + (pl * 32 + qrow) * 128 + ((piece ^ ask_swz(qrow)) << 4));
-        if (qi < p.L) *(__attribute__((address_space(1))) u32x4*)(p.out2 + (long)pl * p.out2_plane + (rowbase + qi) * p.ldo + h * 64 + piece * 8) = v;
+        if (qi < Lq) *(__attribute__((address_space(1))) u32x4*)(p.out2 + (long)pl * p.out2_plane + (rowbase + qi) * p.ldo + h * 64 + piece * 8) = v;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the patch is rewritten by the next tile
     } else {
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
       as_for<8>([&](auto gc) {
         constexpr int db = decltype(gc)::value >> 2, g = decltype(gc)::value & 3, R = AS_O + 32 * T + 16 * db + 4 * g;
         const f32x4 a = {as_agpr<R>() * inv, as_agpr<R + 1>() * inv, as_agpr<R + 2>() * inv, as_agpr<R + 3>() * inv};
-        if (qi < p.L) *(__attribute__((address_space(1))) f32x4*)(p.out + (rowbase + qi) * p.ldo + h * 64 + 4 * half + 32 * db + 8 * g) = a;
+        if (qi < Lq) *(__attribute__((address_space(1))) f32x4*)(p.out + (rowbase + qi) * p.ldo + h * 64 + 4 * half + 32 * db + 8 * g) = a;
       });
     }
   };
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
   if (nkt == 0 && active) {      // an utterance without keys: zeros
     for (int r = lane >> 3; r < QW; r += 8) {
       const int qi = q0 + r, piece = lane & 7;
-      if (qi >= p.L) break;
+      if (qi >= Lq) break;
       if (p.out2) {
         for (int pl = 0; pl < 2; ++pl)
           *(__attribute__((address_space(1))) u32x4*)(p.out2 + (long)pl * p.out2_plane + (rowbase + qi) * p.ldo + h * 64 + piece * 8) = u32x4{0u, 0u, 0u, 0u};
@@ -580,6 +582,9 @@ static int single_qt(const AttnArgs& a) {
 // (640 workgroups: 1.25 rounds run as 2) attn64_pl's small workgroups lose less.  tests/test_gpu_regimes.py holds the seam.
 bool attention64_single_fits(const AttnArgs& a) {
   if (a.B <= 0 || a.L <= 0 || a.chunk != 0) return false;
+  // ragged batch (compact geometry): one workgroup per head is as long as its utterance's keys and queries, and with one round
+  // of workgroups the launch is as long as the longest -- attn64_pl's 128-query workgroups even the lengths out
+  if (a.uoff) return false;
   const long wgs = (long)cdiv(a.L, AS_NW * 32 * single_qt(a)) * a.H * a.B;
   const long slots = (long)cdiv(wgs, 512) * 512;
   return wgs * 100 >= slots * 85;

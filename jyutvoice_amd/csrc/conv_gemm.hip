@@ -372,7 +372,7 @@ int conv_gemm(const ConvGemmArgs& a, int nbatch, hipStream_t st) {
     g.amax_out = nullptr;      // what stays in `out` is what the LayerNorm pass writes
     JV_TRY(conv_gemm(g, 1, st));
     return ln_epilogue_rows(a.out, a.ln_g, a.ln_b, a.ln_eps, a.M, a.N, a.act, a.rowmask_out, a.rowvec, a.row_sample,
-                            a.rowvec_ld, a.res1, a.ldr1, a.out_scale, st, a.amax_out, a.amax_G, a.amax_S, a.amax_nb);
+                            a.rowvec_ld, a.res1, a.ldr1, a.out_scale, st, a.amax_out, a.amax_G, a.amax_S, a.amax_nb, a.amax_rows);
   }
   if (const char* ab = tuning_env("JV_ABLATE")) const_cast<ConvGemmArgs&>(a).ablate = atoi(ab);
   if ((a.W3 || a.W2) && nbatch == 1 && (a.ldw & 7) == 0 && !dyn_env("JV_NO_X6")) return conv_gemm_x6(a, st);

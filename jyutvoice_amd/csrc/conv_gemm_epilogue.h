@@ -22,6 +22,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // M, and rows that amax_mask marks as padding: their values are never read as real frames).
 constexpr int ROW_UNTRACKED = 1 << 30;
 __device__ __forceinline__ int amax_slot(const ConvGemmArgs& p, long row) {
+  if (p.amax_rows) {      // compact geometry: by table (a window row outside the buffer is masked anyway: any slot will do)
+    const long r = row < 0 ? 0 : (row < p.a_rows ? row : p.a_rows - 1);
+    const int s = p.amax_rows[r];
+    return s < 0 ? 0 : (s >= p.amax_nb ? p.amax_nb - 1 : s);
+  }
   if (p.amax_S <= 0) return 0;
   const long s = (row - p.amax_G) / p.amax_S;
   return (int)(s < 0 ? 0 : (s >= p.amax_nb ? p.amax_nb - 1 : s));

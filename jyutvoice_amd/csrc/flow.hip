@@ -56,6 +56,10 @@ struct FlowWs {
   unsigned char* rowmask = nullptr;
   int* row_sample = nullptr;
   int* lens2 = nullptr;     // [2*maxB]
+  // COMPACT geometry of ragged batches (cfm_solve): first row of every utterance (+ the first row past the batch), [2*maxB + 1];
+  // h_lens / h_uoff: pinned host staging (the lengths come down with the solve's one synchronisation, the offsets go up async)
+  int* uoff = nullptr;
+  int *h_lens = nullptr, *h_uoff = nullptr;
   int max_steps = 1024;
   // One Euler step (step scalars -> input assembly -> estimator -> CFG update) captured as a hipGraph per (B, T,
   // attention mode): the step reads its (t, dt) through a device-side counter, so one executable graph replays for
@@ -113,6 +117,9 @@ int flow_ws_create(Context& c) {
   JV_TRY(ws_alloc(c, R, reinterpret_cast<void**>(&w->rowmask)));
   JV_TRY(ws_alloc(c, R * sizeof(int), reinterpret_cast<void**>(&w->row_sample)));
   JV_TRY(ws_alloc(c, (size_t)B2 * sizeof(int), reinterpret_cast<void**>(&w->lens2)));
+  JV_TRY(ws_alloc(c, (size_t)(B2 + 1) * sizeof(int), reinterpret_cast<void**>(&w->uoff)));
+  JV_HIP(hipHostMalloc(reinterpret_cast<void**>(&w->h_lens), (size_t)B2 * sizeof(int), hipHostMallocDefault));
+  JV_HIP(hipHostMalloc(reinterpret_cast<void**>(&w->h_uoff), (size_t)(B2 + 1) * sizeof(int), hipHostMallocDefault));
   JV_TRY(ws_alloc(c, sizeof(int), reinterpret_cast<void**>(&w->step_ctr)));
   JV_TRY(F(&w->t_cur, 1));
   JV_TRY(F(&w->dt_cur, 1));
@@ -163,6 +170,10 @@ struct Geo {
   const float* t_ptr = nullptr;   // timestep per utterance: t_ptr[b * t_stride]
   int t_stride = 1;
   bool temb_pre = false;          // w.temb row 0 already holds this step's embedding, the same for every utterance (cfm_solve)
+  // COMPACT geometry (ragged batches, cfm_solve): utterance b starts at row uoff[b] and owns lens2[b] rows + the gap; M is then
+  // G + sum (len + gap), not G + B2 (T + gap), and every launch of the call is that much shorter.  null: uniform, G + b S + t
+  const int* uoff = nullptr;
+  long alg_rows = 0;              // profiler: real frames of the call (0: B2 * T)
 };
 
 ConvGemmArgs base_args(const Geo& g, const float* A, int lda, const GemmW& w, float* out, int ldo) {
@@ -173,7 +184,7 @@ ConvGemmArgs base_args(const Geo& g, const float* A, int lda, const GemmW& w, fl
   a.W = w.w; a.ldw = w.ldw; a.n_rows_w = w.n_rows; a.N = w.N; a.bias = w.bias;
   a.W3 = w.w3; a.w3_plane = (long)w.n_rows * w.ldw;
   a.out = out; a.ldo = ldo;
-  a.alg_rows = (long)g.B2 * g.T;
+  a.alg_rows = g.alg_rows ? g.alg_rows : (long)g.B2 * g.T;
   return a;
 }
 
@@ -216,7 +227,10 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     if (buf == w.cat || buf == skip) return w.amax + 2 * w.amax_stride;
     return nullptr;
   };
-  auto amax_geo = [&](ConvGemmArgs& a) { a.amax_G = FLOW_G; a.amax_S = g.S; a.amax_nb = B2; a.amax_mask = w.rowmask; };
+  auto amax_geo = [&](ConvGemmArgs& a) {
+    a.amax_G = FLOW_G; a.amax_S = g.S; a.amax_nb = B2; a.amax_mask = w.rowmask;
+    a.amax_rows = g.uoff ? w.row_sample : nullptr;      // compact geometry: a row's slot by table
+  };
   // every launch that writes a trunk buffer tracks max |value| into that buffer's slots (nothing consumes them in
   // exact-range mode)
   auto track = [&](ConvGemmArgs& a) {
@@ -289,7 +303,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     r.W2 = m.w2; r.w2_plane = (long)m.n_rows * m.ldw; r.ldw = m.ldw; r.colscale = m.colscale;
     r.Wf = m.wf; r.wf_plane = (long)m.N * m.ntaps * m.Cin;
     r.amax_in = a.amax_in; r.row_slot = w.row_sample; r.bias = a.bias;
-    r.slot_G = FLOW_G; r.slot_S = g.S; r.slot_nb = B2;      // = row_sample, by arithmetic (row_meta lays utterance b at G + b S)
+    r.slot_G = FLOW_G; r.slot_S = g.uoff ? -1 : g.S; r.slot_nb = B2;      // = row_sample, by arithmetic (row_meta lays utterance b at G + b S; compact: by table)
     r.out = a.out; r.ldo = a.ldo;
     r.ln = a.ln; r.ln_g = a.ln_g; r.ln_b = a.ln_b; r.ln_eps = a.ln_eps; r.act = a.act; r.rowmask_out = a.rowmask_out;
     r.rowvec = a.rowvec; r.rowvec_ld = a.rowvec_ld; r.res = a.res1; r.ldr = a.ldr1;
@@ -415,7 +429,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.W2 = m.w2; a.w2_plane = (long)m.n_rows * m.ldw; a.ldw = m.ldw; a.colscale = m.colscale; a.a_scale = m.a_scale;
     a.Wf = m.wf; a.wf_plane = (long)m.N * m.Cin;
     a.bias = m.bias; a.ln_eps = 1e-5f; a.out2_scale = 1.f;
-    a.alg_rows = (long)g.B2 * g.T;
+    a.alg_rows = g.alg_rows ? g.alg_rows : (long)g.B2 * g.T;
     return a;
   };
   auto rg_track = [&](RowGemmArgs& a) {
@@ -455,7 +469,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     unsigned short* const kv2 = reinterpret_cast<unsigned short*>(w.qkv + R * 512);
     AttnArgs at{};
     at.qkv = w.qkv; at.out = w.att; at.ldo = 512;
-    at.B = B2; at.H = EST_HEADS; at.G = FLOW_G; at.S = g.S; at.L = g.T; at.lens = w.lens2;
+    at.B = B2; at.H = EST_HEADS; at.G = FLOW_G; at.S = g.S; at.L = g.T; at.lens = w.lens2; at.uoff = g.uoff;
     at.chunk = c.attn_chunk;
     at.q_scale = b.q_scale; at.k_scale = b.k_scale; at.v_scale = b.v_scale;
     at.out2 = reinterpret_cast<unsigned short*>(w.att); at.out2_plane = R * 512; at.out2_scale = b.out.a_scale;
@@ -489,7 +503,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
       f.W2f = b.ff2.wf; f.w2f_plane = (long)b.ff2.N * b.ff2.Cin; f.cs2 = b.ff2.colscale; f.b2 = b.ff2.bias;
       f.out = out; f.ldo = ldo;
       f.amax_h = slots_of(h); f.amax_out = slots_of(out); f.row_slot = w.row_sample; f.row_mask = w.rowmask;
-      f.alg_rows = (long)g.B2 * g.T;
+      f.alg_rows = g.alg_rows ? g.alg_rows : (long)g.B2 * g.T;
       const bool follows = next && out == h;
       const bool qkv = follows && qkv_split <= 1;
       if (follows) {
@@ -527,7 +541,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
       f.out = out; f.ldo = ldo; f.res = h; f.ldr = 256;
       f.ln_eps = 1e-5f; f.out2_scale = 1.f;
       if (!c.exact_range) { f.amax_out = slots_of(out); f.row_slot = w.row_sample; f.row_mask = w.rowmask; }
-      f.alg_rows = (long)g.B2 * g.T;
+      f.alg_rows = g.alg_rows ? g.alg_rows : (long)g.B2 * g.T;
       if (next && out == h) {
         f.ln = 1; f.out2 = reinterpret_cast<unsigned short*>(w.ln); f.out2_plane = R * 256; f.ldo2 = 256; f.out2_scale = next->qkv.a_scale;
         f.ln_g = next->n1.g; f.ln_b = next->n1.b;
@@ -568,6 +582,7 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   // `ln_first`: the first block's norm1 planes are already in w.ln (written by the resnet's last convolution)
   auto stage_blocks = [&](const BtbW* blk, float* h, float* last_out, int last_ldo, bool ln_first = false) -> int {
     const bool all = stage_all_rg(blk);
+    if (g.uoff && (!all || c.no_attn_planes)) return fail(JV_ERR_STATE, "flow: the compact geometry exists on the row-owning kernels only");
     bool qkv_ready = false;
     for (int j = 0; j < EST_NBLK; ++j) {
       const bool last = j == EST_NBLK - 1;
@@ -620,6 +635,21 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     JV_TRY(conv_gemm(a, 1, st));
   }
   return JV_OK;
+}
+
+// may a ragged batch of M rows take the compact geometry?  Only the route whose every kernel knows it: the row-owning kernels with
+// the plane attention (flow_compact_ok mirrors estimator_body's own predicates)
+bool flow_compact_ok(const Context& c, long M) {
+  if (c.no_compact || c.exact_range || c.no_rowgemm || c.no_attn_planes || c.attn_chunk != 0 || c.attn_rows || rowgemm_tile((int)M) <= 0) return false;
+  const EstimatorW& e = c.est;
+  for (int i = 0; i < EST_NRES; ++i)
+    for (int j = 0; j < EST_NBLK; ++j) {
+      const BtbW& b = e.blk[i][j];
+      if (!(b.qkv.w2 && b.out.w2 && b.ff1.w2 && b.ff2.w2 && b.qkv.a_scale > 0.f && b.out.a_scale > 0.f && b.ff1.a_scale > 0.f &&
+            b.ff2.a_scale > 0.f && b.q_scale > 0.f))
+        return false;
+    }
+  return true;
 }
 
 int check_shape(Context& c, int B2, int T) {
@@ -698,8 +728,28 @@ int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spk
   }
   JV_HIP(hipMemcpyAsync(w.t_table, tt.data(), sizeof(float) * n_timesteps, hipMemcpyHostToDevice, st));
   JV_HIP(hipMemcpyAsync(w.dt_table, dts.data(), sizeof(float) * n_timesteps, hipMemcpyHostToDevice, st));
+  // Ragged batch?  The lengths come down with the synchronisation below (which the staging vectors need anyway): B ints.
+  const bool ragged_candidate = lens_dev && B > 1 && flow_compact_ok(c, g.M);
+  if (ragged_candidate) JV_HIP(hipMemcpyAsync(w.h_lens, lens_dev, sizeof(int) * B, hipMemcpyDeviceToHost, st));
   // pageable-host staging vectors die at scope exit: make sure the copies have been consumed
   JV_HIP(hipStreamSynchronize(st));
+  // COMPACT geometry: every utterance (and its CFG twin) gets its own frames + the gap, nothing is padded to the longest;
+  // taken when it saves at least 8 % of the rows and the shorter batch still fills the row-owning kernels.  All per-row
+  // arithmetic is the uniform geometry's (a row's sums do not depend on where the row sits): the same bits per utterance.
+  if (ragged_candidate) {
+    long r = FLOW_G, frames = 0;
+    for (int b2 = 0; b2 < B2; ++b2) {
+      const int len = std::min(std::max(w.h_lens[b2 % B], 0), T);
+      w.h_uoff[b2] = (int)r;
+      r += len + FLOW_GAP;
+      frames += len;
+    }
+    w.h_uoff[B2] = (int)r;
+    if (r * 100 <= g.M * 92 && flow_compact_ok(c, r)) {
+      JV_HIP(hipMemcpyAsync(w.uoff, w.h_uoff, sizeof(int) * (B2 + 1), hipMemcpyHostToDevice, st));      // (pinned: stays valid)
+      g.M = r; g.uoff = w.uoff; g.alg_rows = frames;
+    }
+  }
 
   // per-solve preparation: lengths (duplicated for the CFG twin rows), masks, row-layout mu / cond / z
   if (lens_dev) {
@@ -708,11 +758,12 @@ int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spk
   } else {
     JV_TRY(fill_int(w.lens2, T, B2, st));
   }
-  JV_TRY(row_meta(w.rowmask, w.row_sample, w.lens2, B2, 1, FLOW_G, g.S, T, w.rows_alloc, 1, 0, st));
-  JV_TRY(cf_to_rows(mu, 80L * T, T, B, 80, T, w.mu, 80, 0, FLOW_G, g.S, 1.f, nullptr, st));
-  JV_TRY(cf_to_rows(cond, 80L * T, T, B, 80, T, w.cond, 80, 0, FLOW_G, g.S, 1.f, nullptr, st));
+  const int* const clens = g.uoff ? w.lens2 : nullptr;      // (compact: only an utterance's own frames are written)
+  JV_TRY(row_meta(w.rowmask, w.row_sample, w.lens2, B2, 1, FLOW_G, g.S, T, w.rows_alloc, 1, 0, st, g.uoff));
+  JV_TRY(cf_to_rows(mu, 80L * T, T, B, 80, T, w.mu, 80, 0, FLOW_G, g.S, 1.f, clens, st, g.uoff));
+  JV_TRY(cf_to_rows(cond, 80L * T, T, B, 80, T, w.cond, 80, 0, FLOW_G, g.S, 1.f, clens, st, g.uoff));
   // z = rand_noise[:, :, :T] * temperature, the same prefix for every utterance (flow_matching.py:385)
-  JV_TRY(cf_to_rows(c.noise, 0, NOISE_FRAMES, B, 80, T, w.x, 80, 0, FLOW_G, g.S, temperature, nullptr, st));
+  JV_TRY(cf_to_rows(c.noise, 0, NOISE_FRAMES, B, 80, T, w.x, 80, 0, FLOW_G, g.S, temperature, clens, st, g.uoff));
 
   JV_HIP(hipMemsetAsync(w.step_ctr, 0, sizeof(int), st));
   JV_HIP(hipMemsetAsync(w.amax, 0, sizeof(float) * 3 * w.amax_stride, st));      // trunk bounds: maxima over the whole solve
@@ -726,12 +777,12 @@ int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spk
   auto euler_step = [&](hipStream_t s) -> int {
     hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(256), 0, s, w.t_table, w.dt_table, w.step_ctr, w.t_cur, w.dt_cur,
                        g.temb_pre ? w.ts_emb : nullptr, w.temb);
-    JV_TRY(assemble_xin(w.x, w.mu, w.spks, w.cond, w.xin, B, FLOW_G, g.S, T, g.M, s));
+    JV_TRY(assemble_xin(w.x, w.mu, w.spks, w.cond, w.xin, B, FLOW_G, g.S, T, g.M, s, g.uoff, w.row_sample, w.rowmask));
     JV_TRY(estimator_body(c, g, s));
-    return euler_cfg(w.x, w.d, B, FLOW_G, g.S, T, w.dt_cur, 0, 0.7f, s);
+    return euler_cfg(w.x, w.d, B, FLOW_G, g.S, T, w.dt_cur, 0, 0.7f, s, g.uoff, w.lens2);
   };
   // The in-library profiler brackets every launch with events, which a capture would turn into graph nodes: eager then.
-  const bool use_graph = c.step_graphs && !prof_on() && n_timesteps > 1;
+  const bool use_graph = c.step_graphs && !prof_on() && n_timesteps > 1 && !g.uoff;      // (a captured step is keyed by (B, T): uniform geometry only)
   if (!use_graph) {
     for (int s = 0; s < n_timesteps; ++s) JV_TRY(euler_step(st));
   } else {
@@ -807,7 +858,7 @@ int cfm_solve(Context& c, const float* mu, const int* lens_dev, const float* spk
       fprintf(stderr, "\n");
     }
   }
-  return rows_to_cf(w.x, 80, 0, FLOW_G, g.S, mel, 80L * T, B, 80, T, lens_dev ? w.lens2 : nullptr, st);
+  return rows_to_cf(w.x, 80, 0, FLOW_G, g.S, mel, 80L * T, B, 80, T, lens_dev ? w.lens2 : nullptr, st, g.uoff);
 }
 
 }  // namespace jv
@@ -819,6 +870,8 @@ void flow_ws_destroy(Context& c) {
     if (c.flow->gstream) (void)hipStreamDestroy(c.flow->gstream);
     if (c.flow->ev_in) (void)hipEventDestroy(c.flow->ev_in);
     if (c.flow->ev_out) (void)hipEventDestroy(c.flow->ev_out);
+    if (c.flow->h_lens) (void)hipHostFree(c.flow->h_lens);
+    if (c.flow->h_uoff) (void)hipHostFree(c.flow->h_uoff);
   }
   delete c.flow;
   c.flow = nullptr;

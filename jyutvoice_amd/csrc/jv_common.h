@@ -111,6 +111,9 @@ struct ConvGemmArgs {
   // per output row): rows with 0 are padding whose values never reach a real frame and are left out of amax_out.
   int amax_G, amax_S, amax_nb;
   const unsigned char* amax_mask;
+  // the COMPACT geometry of ragged batches (flow.hip): the slot of a row by table (row_meta's row_sample) instead of by
+  // arithmetic -- utterances then start wherever the one before them ended
+  const int* amax_rows;
   // split-K for short M (flow.hip: a single utterance is 20 tiles of 64x64 x 32 dependent K steps otherwise): grid.y = ksplit
   // workgroups per tile each contract a contiguous share of the 32-channel chunks and write a plain fp32 partial to
   // out + y * split_stride (the caller points `out` at a partial-sum workspace and leaves bias / epilogue to
@@ -185,6 +188,8 @@ struct AttnArgs {
   long ldo;
   int B, H;
   int G, S, L;        // row geometry: utterance b, frame t at row G + b*S + t, t < L
+  const int* uoff;    // optional (attention64_planes / attention64_single only): the COMPACT geometry of ragged batches -- utterance b
+                      // starts at row uoff[b] (device, [B]) and owns lens[b] rows: queries past lens[b] are the next utterance's rows
   const int* lens;    // [B] valid keys per utterance (device), or null = L
   // fp16x3 contractions (attention.hip, NP = 2) when q_scale > 0: exact powers of two with |q| log2(e)/8 * q_scale,
   // |k| * k_scale, |v| * v_scale < 65504 PROVEN by the caller; 0 = bf16x6, any fp32 operand

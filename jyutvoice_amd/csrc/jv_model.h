@@ -57,7 +57,13 @@ struct GemmW {
 
 struct LnW { const float* g = nullptr; const float* b = nullptr; };
 
-struct ResnetW { GemmW block1, block2, res; LnW ln1, ln2; };
+struct ResnetW {
+  GemmW block1, block2, res;
+  LnW ln1, ln2;
+  // block1's three taps AND res_conv as a fourth fragment step per 32-channel chunk (k-step major fragments: steps 0 .. 3 NCH - 1
+  // are block1's, 3 NCH .. 4 NCH - 1 res_conv's), plane stride 256 * 4 * Cin halves: rowconv_wd_kernel<RT, true> (registry.hip)
+  const unsigned short* wf4 = nullptr;
+};
 struct BtbW {
   LnW n1, n3;
   GemmW qkv, out, ff1, ff2;
@@ -134,6 +140,7 @@ struct Context {
   bool no_ffn_fuse = false;      // JV_NO_FFN_FUSE=1: ff.net.0 and ff.net.2 as two launches (the path rowffn_kernel is checked against)
   bool no_temb_pre = false;      // JV_NO_TEMB_PRE=1: the timestep embedding inside every Euler step instead of once per solve (flow.hip cfm_solve)
   bool no_ln_fold = false;       // JV_NO_LN_FOLD=1: a stage's first norm1 as its own launch (layernorm256_planes) instead of in the resnet's last convolution
+  bool no_compact = false;       // JV_NO_COMPACT=1: ragged batches keep the uniform row geometry (every utterance padded to the longest; flow.hip cfm_solve)
   bool no_qkv_split = false;     // JV_NO_QKV_SPLIT=1: q|k|v stays inside the fused block launch at every batch size (flow.hip `qkv_split`)
   bool no_block_fuse = false;    // JV_NO_BLOCK_FUSE=1: to_out / feed-forward / next q|k|v as three launches (the path rowblock_kernel is checked against)
   bool rg_ff1 = true;            // ff.net.0 on the row-owning GEMM too; JV_TILE_FF1=1: on the tile kernel (the round-2 first build, for A/B runs)

@@ -445,6 +445,23 @@ struct Packer {
     }
     g.wf = reinterpret_cast<const unsigned short*>(d);
   }
+  // a resnet's block1 (k = 3) and its 1 x 1 res_conv read the same rows: one fragment stream for both (ResnetW::wf4)
+  void wfrag4(ResnetW& r) {
+    const GemmW &b = r.block1, &q = r.res;
+    if (rc != JV_OK || !b.w2 || !q.w2 || !b.wf || b.ntaps != 3 || q.ntaps != 1 || b.Cin != q.Cin || b.N != 256 || q.N != 256 ||
+        (b.Cin & 63) || b.ldw != 3 * b.Cin || q.ldw != q.Cin) return;
+    const int Cin = b.Cin, NCH = Cin >> 5;
+    const long plane = 256L * 4 * Cin;      // halves
+    float* d = alloc((size_t)plane + 8);
+    if (!d) return;
+    unsigned short* const wf = reinterpret_cast<unsigned short*>(d);
+    if (pack_wfrag(b.w2, (long)b.n_rows * b.ldw, b.ldw, 256, 3 * Cin, wf, plane, st) != JV_OK ||
+        pack_wfrag(q.w2, (long)q.n_rows * q.ldw, q.ldw, 256, Cin, wf + 3L * NCH * 16 * 512, plane, st) != JV_OK) {
+      rc = JV_ERR_HIP;
+      return;
+    }
+    r.wf4 = wf;
+  }
   // conv weight [cout][cin][k] (device, plain) -> GemmW with cin padded to cinp
   GemmW conv(const float* w, int cout, int cin, int k, int cinp, const float* bias) {
     GemmW g;
@@ -601,6 +618,7 @@ int finalize_model(Context& c, int model, hipStream_t st) {
       (void)pk.half3(e.res[i].block2);
       pk.wfrag(e.res[i].block1); pk.wfrag(e.res[i].block2);
       (void)pk.half3(e.res[i].res);
+      pk.wfrag4(e.res[i]);
       for (int j = 0; j < EST_NBLK; ++j) {
         const std::string b = stage[i] + "1." + S(j) + ".";
         BtbW& w = e.blk[i][j];

@@ -34,11 +34,15 @@ int rb_launch(const RowBlockArgs& a, hipStream_t st) {
   return JV_OK;
 }
 
-// JV_NO_FF_STAGGER=1: the feed-forward with every wave in the same phase (the schedule before round 4; same results, for A/B runs)
+// JV_FF_STAGGER=1: the feed-forward with waves 0..3 half a hidden chunk ahead of waves 4..7 (rowblock_kernel.h, STAG; the same
+// bits).  Measured SLOWER than every wave in the same phase (133.8 against 129.4 us per launch, same box): a wave that runs
+// its MFMA steps alone on a SIMD takes ~930 cycles per step, not 480 -- its weight fragments are requested 1.5 steps ahead,
+// which at one wave per SIMD is less than an L2 round trip -- so the half that computes beside the other half's GELU pass
+// takes as long as both halves computing together.  Kept as a tested alternative.
 bool ff_stagger() {
-  static const bool off = getenv("JV_NO_FF_STAGGER") != nullptr;
-  const char* d = dyn_env("JV_NO_FF_STAGGER");
-  return !(off || (d && d[0] == '1'));
+  static const bool on = getenv("JV_FF_STAGGER") != nullptr;
+  const char* d = dyn_env("JV_FF_STAGGER");
+  return on || (d && d[0] == '1');
 }
 
 template <int RT>

@@ -29,7 +29,7 @@ struct RowConvArgs {
   const float* colscale;
   const float* amax_in;          // per-utterance bound of A (slot = row_slot[row])
   const int* row_slot;
-  int slot_G, slot_S, slot_nb;   // the same slots by arithmetic, clamp((row - slot_G) / slot_S, 0, slot_nb - 1) (slot_S = 0: slot 0):
+  int slot_G, slot_S, slot_nb;   // (slot_S < 0: no arithmetic, row_slot is read -- the compact geometry of ragged batches) the same slots by arithmetic, clamp((row - slot_G) / slot_S, 0, slot_nb - 1) (slot_S = 0: slot 0):
                                  // rowconv_wd_kernel computes them instead of loading row_slot (one level of dependent loads less)
   const float* bias;
   float* out;
@@ -52,6 +52,13 @@ struct RowConvArgs {
   long ln2_plane;
   const float *ln2_g, *ln2_b;
   float ln2_scale;
+  // rowconv_wd_kernel<RT, true>: the resnet's 1 x 1 res_conv (decoder.py:110-115: output = block2(..) + res_conv(x * mask)) computed
+  // by block1's launch, which stages the very rows res_conv reads: Wf then holds FOUR fragment steps per 32-channel chunk --
+  // the three taps and, as a fourth, res_conv's chunk -- the fourth step multiplies the window at the row offset of tap 2 (the
+  // output row itself) into a second accumulator, and a second slab pass stores res_out = acc_r * res_cs / a_scale + res_bias
+  // (fp32 rows [., 256]) for block2's launch to add.  Replaces a tile-kernel launch per resnet and its re-read of the input.
+  float* res_out;
+  const float *res_cs, *res_bias;
   long alg_rows;
   int ablate;      // tuning aid (JV_RG_ABLATE, tuning builds): 1 no weight DMA in the loop, 2 no LDS reads + MFMAs, 4 no waits / barriers,
                    // 8 no A staging in the loop, 16 no epilogue
@@ -357,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void rowconv_kernel(const RowConvArgs p) {
 template <int RT> constexpr int rcw_slab_off() { return (2 * 2 * rc_a_plane<RT>() + 16 * RT * 8 + 255) & ~255; }
 template <int RT> constexpr int rcw_lds_bytes() { return rcw_slab_off<RT>() + 16 * RT * RG_SLD * 4; }
 
-template <int RT>
+template <int RT, bool RES>
 __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rc_lds[];
   constexpr int R = 16 * RT, WR = R + 2;
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
   const int r16 = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.x * R;
   const int NCH = p.Cin >> 5;
-  const int total = 3 * NCH;
+  constexpr int NJ = RES ? 4 : 3;      // fragment steps per chunk: the taps (+ res_conv's chunk)
   int stamp_i = 0;
   auto stamp = [&]() {      // (compiled out unless JV_TUNING)
     if (JV_STAMP(p)) {
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
   // warm this XCD's L2 with the weight planes (see rowgemm_kernel.h)
   float warm = 0.f;
   {
-    const long lpp = ((long)256 * 3 * p.Cin * 2) >> 7;
+    const long lpp = ((long)256 * NJ * p.Cin * 2) >> 7;
     const int grp = blockIdx.x >> 3, ngrp = (gridDim.x + 7) >> 3;
     const long per = (2 * lpp + ngrp - 1) / ngrp;
     const long l = (long)grp * per + tid;
@@ -393,9 +400,8 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
     }
   }
 
-  // ---- W: fragment order over K = 3 Cin (k = j Cin + 32 c is fragment step j NCH + c), a register double buffer loaded by
+  // ---- W: fragment order over K = NJ Cin (k = j Cin + 32 c is fragment step j NCH + c), a register double buffer loaded by
   // inline asm with counted waits -- rowgemm_wd_kernel's, including its rules (tools/check_rowgemm_isa.py covers this kernel)
-  const int KSW = 3 * NCH;
   const unsigned short* wbase[2][2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
@@ -417,11 +423,11 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
   auto landed_w = [](rg_u32x4& b00, rg_u32x4& b01, rg_u32x4& b10, rg_u32x4& b11) {
     asm volatile("" : "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11)::"memory");
   };
-  auto advance_w = [&]() {      // (c, j) -> (c, j + 1): + NCH steps; (c, 2) -> (c + 1, 0): + 1 - 2 NCH; past the end: back to 0
-    if (++wj == 3) {
+  auto advance_w = [&]() {      // (c, j) -> (c, j + 1): + NCH steps; (c, NJ - 1) -> (c + 1, 0): + 1 - (NJ - 1) NCH; past the end: back to 0
+    if (++wj == NJ) {
       wj = 0;
       if (++wc == NCH) { wc = 0; woff = 0; }
-      else woff += (1L - 2L * NCH) * (16 * 512);
+      else woff += (1L - (long)(NJ - 1) * NCH) * (16 * 512);
     } else {
       woff += (long)NCH * (16 * 512);
     }
@@ -444,6 +450,10 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
   int2* const rowinfo = reinterpret_cast<int2*>(rc_lds + A_OFF + 2 * A_BUF);      // 8 R bytes, then the slab
   constexpr int RI_KEEP = 1 << 29, RI_TRACK = 1 << 30;
   auto slot_of = [&](const long row) -> int {
+    if (p.slot_S < 0) {      // compact geometry (ragged batches): by table; `row` is clamped to the buffer by every caller
+      const int q = p.row_slot[row];
+      return q < 0 ? 0 : (q >= p.slot_nb ? p.slot_nb - 1 : q);
+    }
     if (p.slot_S <= 0) return 0;
     const int q = (int)((row - p.slot_G) / p.slot_S);
     return q < 0 ? 0 : (q >= p.slot_nb ? p.slot_nb - 1 : q);
@@ -523,11 +533,14 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
     for (int i = 0; i < NI; ++i) ascale[i] = (ok[i] && mk_i[i] != 0) ? h3_scale_dev(am_i[i]) : 0.f;
   }
 
-  rg_f32x4 acc[RT][2];
+  rg_f32x4 acc[RT][2], accr[RES ? RT : 1][2];      // accr: res_conv's product (RES)
 #pragma unroll
   for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < 2; ++nt) {
+      acc[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (RES) accr[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
   // the epilogue's per-column constants, fetched here so that their latency is not paid behind the main loop
   const rg_f32x4 cs4 = *reinterpret_cast<const rg_f32x4*>(p.colscale + 4 * lane);
@@ -537,6 +550,11 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
   if (p.ln) {
     gg = *reinterpret_cast<const rg_f32x4*>(p.ln_g + 4 * lane);
     bb = *reinterpret_cast<const rg_f32x4*>(p.ln_b + 4 * lane);
+  }
+  rg_f32x4 csr4 = {0.f, 0.f, 0.f, 0.f}, br4 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (RES) {
+    csr4 = *reinterpret_cast<const rg_f32x4*>(p.res_cs + 4 * lane);
+    if (p.res_bias) br4 = *reinterpret_cast<const rg_f32x4*>(p.res_bias + 4 * lane);
   }
   stamp();      // 1: row facts and staging addresses set up
   rg_wait_vmcnt<0>();      // the first window's rows (and the first fragments, needed two lines down anyway)
@@ -555,8 +573,9 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
   // the wait: W0(s+1) and W1(s); behind W0(s+1): W1(s+1), the A loads where step s - 1 issued them, W0(s+2).  The window
   // changes per CHUNK, not per step: one workgroup barrier per chunk (three in the LDS-ring form, whose weight stages
   // needed one per step).  Past the end of the launch the W loads wrap around to weights that exist.
-  auto step = [&](auto par_tag, const int c, const int j) {
-    constexpr int par = decltype(par_tag)::value;
+  auto step = [&](auto par_tag, const int c, auto jtag) {
+    constexpr int par = decltype(par_tag)::value, j = decltype(jtag)::value;
+    constexpr int jrow = j < 3 ? j : 2;      // res_conv's step reads the output row itself: tap 2's row offset
     if (j == 0) {
       rg_lds_barrier();      // every thread's plane stores of this chunk's window are complete; the other buffer is free
       if (c + 1 < NCH) {      // its registers were loaded a chunk ago and waited for at step (c - 1, 2) ...
@@ -569,44 +588,59 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
     rg_u32x4 af[RT][2];
 #pragma unroll
     for (int mt = 0; mt < RT; ++mt) {
-      const int row = mt * 16 + r16 + j;
+      const int row = mt * 16 + r16 + jrow;
       const int a_off = row * 64 + ((kq ^ rg_key(row)) << 4);
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) af[mt][pl] = *reinterpret_cast<const rg_u32x4*>(sa + pl * A_PLANE + a_off);
     }
     __builtin_amdgcn_sched_barrier(0);
-    auto block = [&](auto nttag) {
+    auto block = [&](auto nttag, rg_f32x4 (&ac)[RT][2]) {
       constexpr int nt = decltype(nttag)::value;
 #pragma unroll
       for (int mt = 0; mt < RT; ++mt) {
-        rg_f32x4 t = acc[mt][nt];
+        rg_f32x4 t = ac[mt][nt];
         auto mm = [&](const rg_u32x4& x, const rg_u32x4& y) {
           t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rg_f16x8, x), __builtin_bit_cast(rg_f16x8, y), t, 0, 0, 0);
         };
         mm(af[mt][1], bq[par][nt][0]);
         mm(af[mt][0], bq[par][nt][1]);
         mm(af[mt][0], bq[par][nt][0]);
-        acc[mt][nt] = t;
+        ac[mt][nt] = t;
       }
       __builtin_amdgcn_sched_barrier(0);
       load_w(par_tag, nttag);
       __builtin_amdgcn_sched_barrier(0);
     };
-    block(std::integral_constant<int, 0>{});
+    rg_f32x4 (&ac)[RT][2] = (j == 3) ? accr : acc;      // (j is a compile-time constant: no selection at run time)
+    block(std::integral_constant<int, 0>{}, ac);
     if (j == 1 && c + 2 < NCH) rg_wait_vmcnt<NWL + NI>(); else rg_wait_vmcnt<NWL>();
     landed_w(bq[par][1][0], bq[par][1][1], bq[par ^ 1][0][0], bq[par ^ 1][0][1]);
-    block(std::integral_constant<int, 1>{});
+    block(std::integral_constant<int, 1>{}, ac);
     advance_w();
     if (j == 0 && c + 2 < NCH) load_A(c + 2);      // behind this step's weight loads (the wait counts above rely on it)
   };
+  typedef std::integral_constant<int, 0> J0;
+  typedef std::integral_constant<int, 1> J1;
+  typedef std::integral_constant<int, 2> J2;
+  typedef std::integral_constant<int, 3> J3;
+  if constexpr (RES) {
 #pragma unroll 1
-  for (int c = 0; c < NCH; c += 2) {      // NCH is even: two chunks = six steps, parities 0 1 0 1 0 1
-    step(std::integral_constant<int, 0>{}, c, 0);
-    step(std::integral_constant<int, 1>{}, c, 1);
-    step(std::integral_constant<int, 0>{}, c, 2);
-    step(std::integral_constant<int, 1>{}, c + 1, 0);
-    step(std::integral_constant<int, 0>{}, c + 1, 1);
-    step(std::integral_constant<int, 1>{}, c + 1, 2);
+    for (int c = 0; c < NCH; ++c) {      // four steps per chunk: parities 0 1 0 1
+      step(std::integral_constant<int, 0>{}, c, J0{});
+      step(std::integral_constant<int, 1>{}, c, J1{});
+      step(std::integral_constant<int, 0>{}, c, J2{});
+      step(std::integral_constant<int, 1>{}, c, J3{});
+    }
+  } else {
+#pragma unroll 1
+    for (int c = 0; c < NCH; c += 2) {      // NCH is even: two chunks = six steps, parities 0 1 0 1 0 1
+      step(std::integral_constant<int, 0>{}, c, J0{});
+      step(std::integral_constant<int, 1>{}, c, J1{});
+      step(std::integral_constant<int, 0>{}, c, J2{});
+      step(std::integral_constant<int, 1>{}, c + 1, J0{});
+      step(std::integral_constant<int, 0>{}, c + 1, J1{});
+      step(std::integral_constant<int, 1>{}, c + 1, J2{});
+    }
   }
 
   // ---- epilogue: the whole tile through ONE slab laid over the (now idle) weight ring -- a single chunk has nothing left to
@@ -743,6 +777,26 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
     stamp();      // 5: first row group done
     rows(std::integral_constant<int, 1>{}, in1);
     stamp();      // 6: second row group done
+  }
+  if constexpr (RES) {
+    // ---- res_conv's rows: a second pass through the same slab -- res_out = acc_r * res_cs / a_scale + res_bias, fp32 rows that
+    // block2's launch adds.  (A masked input row was staged as zeros: its output is the bias, as in a launch of its own.)
+    rg_lds_barrier();      // every wave has read its rows of the first pass
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) slab[(mt * 16 + kq * 4 + e) * RG_SLD + wave * 32 + nt * 16 + r16] = accr[mt][nt][e];
+    rg_lds_barrier();
+#pragma unroll
+    for (int jj = 0; jj < 2 * RT; ++jj) {
+      const int trow = wave * 2 * RT + jj;
+      const long mrow = (long)m0 + trow;
+      const float inv = __uint_as_float((unsigned)rowinfo[trow].x);
+      const rg_f32x4 v = *reinterpret_cast<const rg_f32x4*>(slab + trow * RG_SLD + 4 * lane) * (csr4 * inv) + br4;
+      if (mrow < p.M) *(__attribute__((address_space(1))) rg_f32x4*)(p.res_out + mrow * 256 + 4 * lane) = v;
+    }
   }
   rg_wait_vmcnt<0>();      // the wrapped-around W loads: bq stays reserved until they have landed (rowgemm_wd_kernel)
   landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);

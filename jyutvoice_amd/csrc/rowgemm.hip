@@ -151,20 +151,26 @@ int rc_launch(const RowConvArgs& a, hipStream_t st) {
   static bool raised_wd[64] = {};
   const bool wdir = rowconv_w_direct(a);
   if (a.ln2_out && !wdir) return fail(JV_ERR_ARG, "rowconv: the following LayerNorm exists on the W-direct kernel only");
+  if (a.res_out && !wdir) return fail(JV_ERR_ARG, "rowconv: the folded res_conv exists on the W-direct kernel only");
   if (wdir && !raised_wd[dev & 63]) {
-    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowconv_wd_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowconv_wd_kernel<RT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               rcw_lds_bytes<RT>()));
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowconv_wd_kernel<RT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                rcw_lds_bytes<RT>()));
     raised_wd[dev & 63] = true;
   }
   const bool prof = prof_on();
   if (prof) prof_begin(st);
-  if (wdir) hipLaunchKernelGGL((rowconv_wd_kernel<RT>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rcw_lds_bytes<RT>(), st, a);
+  if (wdir && a.res_out) hipLaunchKernelGGL((rowconv_wd_kernel<RT, true>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rcw_lds_bytes<RT>(), st, a);
+  else if (wdir) hipLaunchKernelGGL((rowconv_wd_kernel<RT, false>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rcw_lds_bytes<RT>(), st, a);
   else hipLaunchKernelGGL((rowconv_kernel<RT>), dim3(cdiv(a.M, 16 * RT)), dim3(512), rc_lds_bytes<RT>(), st, a);
   if (prof) {
     static const std::string name = std::string("rowconv_h3<") + std::to_string(16 * RT) + "x256,k3>";
+    static const std::string name_res = std::string("rowconv_h3<") + std::to_string(16 * RT) + "x256,k3+res>";
     const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M);
-    const double bytes = 4.0 * (rows * a.Cin + 256.0 * 3 * a.Cin + rows * 256 * (a.res ? 2 : 1));
-    prof_end(st, name.c_str(), 2.0 * rows * 256.0 * 3 * a.Cin, bytes);
+    const int taps = a.res_out ? 4 : 3;      // (the folded 1 x 1 res_conv is a fourth tap's worth of work and one more output)
+    const double bytes = 4.0 * (rows * a.Cin + 256.0 * taps * a.Cin + rows * 256 * ((a.res ? 2 : 1) + (a.res_out ? 1 : 0)));
+    prof_end(st, (a.res_out ? name_res : name).c_str(), 2.0 * rows * 256.0 * taps * a.Cin, bytes);
   }
   JV_HIP(hipGetLastError());
   return JV_OK;
@@ -180,6 +186,7 @@ int rowconv(const RowConvArgs& a, hipStream_t st) {
   if ((a.Cin & 31) || a.Cin < 32 || (a.lda & 3) || (a.ldw & 7) || (a.ldo & 3) || (a.res && (a.ldr & 3)) || (a.rowvec && (a.rowvec_ld & 3)))
     return fail(JV_ERR_ARG, "rowconv: Cin % 32 == 0 and aligned strides required");
   if (a.ln && (!a.ln_g || !a.ln_b)) return fail(JV_ERR_ARG, "rowconv: LayerNorm needs gain and offset");
+  if (a.res_out && !a.res_cs) return fail(JV_ERR_ARG, "rowconv: the folded res_conv needs its column scales");
   if (a.ln2_out && (!a.ln2_g || !a.ln2_b || !(a.ln2_scale > 0.f) || a.ln2_plane <= 0 || a.ldo != 256))
     return fail(JV_ERR_ARG, "rowconv: the following LayerNorm needs gain, offset, a scale, a plane stride and 256-wide output rows");
   int rt = rowgemm_tile(a.M);

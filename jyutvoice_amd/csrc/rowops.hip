@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void ln_epilogue_kernel(float* __restrict__ x,
                                                           const unsigned char* __restrict__ rowmask,
                                                           const float* __restrict__ rowvec, const int* __restrict__ row_sample,
                                                           int rowvec_ld, const float* __restrict__ res, long ldr, float scale,
-                                                          float* __restrict__ amax_out, int amax_G, int amax_S, int amax_nb) {
+                                                          float* __restrict__ amax_out, int amax_G, int amax_S, int amax_nb,
+                                                          const int* __restrict__ amax_rows) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -153,7 +154,10 @@ __global__ __launch_bounds__(256) void ln_epilogue_kernel(float* __restrict__ x,
   float sum = 0.f;
   unsigned amax = 0u;      // max |value written|, as conv_gemm's epilogue tracks it (ConvGemmArgs::amax_out)
   // the row's utterance owns the slot (ConvGemmArgs::amax_G/S/nb); rows the mask marks as padding are not tracked
-  if (amax_out && amax_S > 0) {
+  if (amax_out && amax_rows) {      // compact geometry (ConvGemmArgs::amax_rows)
+    const int sl = amax_rows[row];
+    amax_out += sl < 0 ? 0 : (sl >= amax_nb ? amax_nb - 1 : sl);
+  } else if (amax_out && amax_S > 0) {
     const long sl = (row - amax_G) / amax_S;
     amax_out += sl < 0 ? 0 : (sl >= amax_nb ? amax_nb - 1 : sl);
   }
@@ -213,7 +217,8 @@ __global__ __launch_bounds__(256) void ln_epilogue_kernel(float* __restrict__ x,
 
 int ln_epilogue_rows(float* x, const float* g, const float* b, float eps, long rows, int C, int act,
                      const unsigned char* rowmask, const float* rowvec, const int* row_sample, int rowvec_ld, const float* res,
-                     long ldr, float scale, hipStream_t st, float* amax_out, int amax_G, int amax_S, int amax_nb) {
+                     long ldr, float scale, hipStream_t st, float* amax_out, int amax_G, int amax_S, int amax_nb,
+                     const int* amax_rows) {
   if (rows <= 0) return JV_OK;
   if ((C & 3) || C > 1024 || (rowvec && (rowvec_ld & 3)) || (res && (ldr & 3)))
     return fail(JV_ERR_ARG, "ln_epilogue_rows: C, rowvec_ld and ldr must be multiples of 4 (C <= 1024)");
@@ -222,10 +227,10 @@ int ln_epilogue_rows(float* x, const float* g, const float* b, float eps, long r
   if (prof) prof_begin(st);
   if (C <= 256)
     hipLaunchKernelGGL((ln_epilogue_kernel<1>), grid, dim3(256), 0, st, x, g, b, eps, rows, C, act, rowmask, rowvec, row_sample,
-                       rowvec_ld, res, ldr, scale, amax_out, amax_G, amax_S, amax_nb);
+                       rowvec_ld, res, ldr, scale, amax_out, amax_G, amax_S, amax_nb, amax_rows);
   else
     hipLaunchKernelGGL((ln_epilogue_kernel<4>), grid, dim3(256), 0, st, x, g, b, eps, rows, C, act, rowmask, rowvec, row_sample,
-                       rowvec_ld, res, ldr, scale, amax_out, amax_G, amax_S, amax_nb);
+                       rowvec_ld, res, ldr, scale, amax_out, amax_G, amax_S, amax_nb, amax_rows);
   if (prof) prof_end(st, "ln_epilogue", 0.0, 4.0 * rows * C * (res ? 3 : 2));
   JV_HIP(hipGetLastError());
   return JV_OK;
@@ -294,14 +299,30 @@ int splitk_reduce_rows(const SplitKReduceArgs& a, hipStream_t st) {
 }
 
 // ---- row metadata: rowmask[r] (1 = real frame) and row_sample[r] (utterance index) -----------------
+// Two geometries.  Uniform (uoff == null): utterance b, frame t at row G + b S + t.  COMPACT (uoff != null, ragged batches,
+// flow.hip): utterance b starts at row uoff[b] and owns lens[b % nb] rows + the gap up to uoff[b + 1] -- no row is spent on
+// padding an utterance to the longest (uoff has nb * reps + 1 entries, the last one = the first row past the batch).
 __global__ void row_meta_kernel(unsigned char* rowmask, int* row_sample, const int* lens, int nb, int reps, int G, int S,
-                                int L, long rows, int mul, int add) {
+                                int L, long rows, int mul, int add, const int* __restrict__ uoff) {
   const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
+  const int B = nb * reps;
+  if (uoff) {
+    // binary search: the last utterance whose first row is <= r (rows ahead of the first utterance: utterance 0, masked)
+    int lo = 0, hi = B - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (uoff[mid] <= r) lo = mid; else hi = mid - 1;
+    }
+    const long t = r - uoff[lo];
+    const bool ok = t >= 0 && r < uoff[B] && t < (lens ? (long)lens[lo % nb] * mul + add : (long)L);
+    rowmask[r] = ok ? 1 : 0;
+    if (row_sample) row_sample[r] = lo;
+    return;
+  }
   const long rel = r - G;
   int b = rel >= 0 ? (int)(rel / S) : 0;
   const int t = rel >= 0 ? (int)(rel - (long)b * S) : -1;
-  const int B = nb * reps;
   bool ok = rel >= 0 && b < B && t < L;
   if (b >= B) b = B - 1;
   if (ok && lens) ok = t < lens[b % nb] * mul + add;
@@ -310,9 +331,9 @@ __global__ void row_meta_kernel(unsigned char* rowmask, int* row_sample, const i
 }
 
 int row_meta(unsigned char* rowmask, int* row_sample, const int* lens, int nb, int reps, int G, int S, int L, long rows,
-             int mul, int add, hipStream_t st) {
+             int mul, int add, hipStream_t st, const int* uoff) {
   hipLaunchKernelGGL(row_meta_kernel, dim3((unsigned)cdivl(rows, 256)), dim3(256), 0, st, rowmask, row_sample, lens, nb,
-                     reps, G, S, L, rows, mul, add);
+                     reps, G, S, L, rows, mul, add, uoff);
   JV_HIP(hipGetLastError());
   return JV_OK;
 }
@@ -320,11 +341,15 @@ int row_meta(unsigned char* rowmask, int* row_sample, const int* lens, int nb, i
 // ---- channels-first [B,C,T] <-> row buffer [G + b*S + t][ld] (LDS-tiled transpose) ----------------
 __global__ __launch_bounds__(256) void cf_to_rows_kernel(const float* __restrict__ src, long src_bstride, long pitch, int C,
                                                          int T, float* __restrict__ dst, int ld, int col0, int G, int S,
-                                                         float scale, const int* __restrict__ lens) {
+                                                         float scale, const int* __restrict__ lens, const int* __restrict__ uoff) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   const int tmax = lens ? min(lens[b], T) : T;
+  // compact geometry: an utterance owns its own frames only (the rows behind them are the next utterance's)
+  const long row0 = uoff ? (long)uoff[b] : (long)G + (long)b * S;
+  const int twr = uoff ? tmax : T;
+  if (t0 >= twr) return;      // (uniform over the block)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = c0 + ty + 8 * i, t = t0 + tx;
@@ -334,30 +359,32 @@ __global__ __launch_bounds__(256) void cf_to_rows_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int t = t0 + ty + 8 * i, c = c0 + tx;
-    if (t < T && c < C) dst[((long)G + (long)b * S + t) * ld + col0 + c] = tile[tx][ty + 8 * i];
+    if (t < twr && c < C) dst[(row0 + t) * ld + col0 + c] = tile[tx][ty + 8 * i];
   }
 }
 
 int cf_to_rows(const float* src, long src_bstride, long pitch, int B, int C, int T, float* dst, int ld, int col0, int G,
-               int S, float scale, const int* lens, hipStream_t st) {
+               int S, float scale, const int* lens, hipStream_t st, const int* uoff) {
   if (B <= 0 || T <= 0) return JV_OK;
+  if (uoff && !lens) return fail(JV_ERR_ARG, "cf_to_rows: the compact geometry needs the lengths");
   hipLaunchKernelGGL(cf_to_rows_kernel, dim3(cdiv(T, 32), cdiv(C, 32), B), dim3(256), 0, st, src, src_bstride, pitch, C, T,
-                     dst, ld, col0, G, S, scale, lens);
+                     dst, ld, col0, G, S, scale, lens, uoff);
   JV_HIP(hipGetLastError());
   return JV_OK;
 }
 
 __global__ __launch_bounds__(256) void rows_to_cf_kernel(const float* __restrict__ src, int ld, int col0, int G, int S,
                                                          float* __restrict__ dst, long dst_bstride, int C, int T,
-                                                         const int* __restrict__ lens) {
+                                                         const int* __restrict__ lens, const int* __restrict__ uoff) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int tmax = lens ? min(lens[b], T) : T;
+  const long row0 = uoff ? (long)uoff[b] : (long)G + (long)b * S;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int t = t0 + ty + 8 * i, c = c0 + tx;
-    tile[ty + 8 * i][tx] = (t < tmax && c < C) ? src[((long)G + (long)b * S + t) * ld + col0 + c] : 0.f;
+    tile[ty + 8 * i][tx] = (t < tmax && c < C) ? src[(row0 + t) * ld + col0 + c] : 0.f;
   }
   __syncthreads();
 #pragma unroll
@@ -368,10 +395,11 @@ __global__ __launch_bounds__(256) void rows_to_cf_kernel(const float* __restrict
 }
 
 int rows_to_cf(const float* src, int ld, int col0, int G, int S, float* dst, long dst_bstride, int B, int C, int T,
-               const int* lens, hipStream_t st) {
+               const int* lens, hipStream_t st, const int* uoff) {
   if (B <= 0 || T <= 0) return JV_OK;
+  if (uoff && !lens) return fail(JV_ERR_ARG, "rows_to_cf: the compact geometry needs the lengths");
   hipLaunchKernelGGL(rows_to_cf_kernel, dim3(cdiv(T, 32), cdiv(C, 32), B), dim3(256), 0, st, src, ld, col0, G, S, dst,
-                     dst_bstride, C, T, lens);
+                     dst_bstride, C, T, lens, uoff);
   JV_HIP(hipGetLastError());
   return JV_OK;
 }
@@ -381,7 +409,9 @@ int rows_to_cf(const float* src, int ld, int col0, int G, int S, float* dst, lon
 // jyutvoice/flow/flow_matching.py:246-251.  x/mu/cond are row buffers of 80 columns with geometry (G,S).
 __global__ __launch_bounds__(256) void assemble_xin_kernel(const float* __restrict__ x, const float* __restrict__ mu,
                                                            const float* __restrict__ spks, const float* __restrict__ cond,
-                                                           float* __restrict__ xin, int B, int G, int S, int L, long rows2) {
+                                                           float* __restrict__ xin, int B, int G, int S, int L, long rows2,
+                                                           const int* __restrict__ uoff, const int* __restrict__ row_sample,
+                                                           const unsigned char* __restrict__ rowmask) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // one f32x4 (4 of 320 columns) per thread
   const long r = idx / 80;
   const int c4 = (int)(idx - r * 80);
@@ -389,12 +419,13 @@ __global__ __launch_bounds__(256) void assemble_xin_kernel(const float* __restri
   const long rel = r - G;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (rel >= 0) {
-    const int b2 = (int)(rel / S);
-    const int t = (int)(rel - (long)b2 * S);
+    // compact geometry (row_meta): the row's utterance and validity come from the row tables, its frame from uoff
+    const int b2 = uoff ? row_sample[r] : (int)(rel / S);
+    const int t = uoff ? (rowmask[r] ? (int)(r - uoff[b2]) : L) : (int)(rel - (long)b2 * S);
     if (b2 < 2 * B && t < L) {
       const bool un = b2 >= B;
       const int b = un ? b2 - B : b2;
-      const long sr = (long)G + (long)b * S + t;
+      const long sr = uoff ? (long)uoff[b] + t : (long)G + (long)b * S + t;
       const int part = c4 / 20, cc = (c4 % 20) * 4;
       if (part == 0) v = *reinterpret_cast<const f32x4*>(x + sr * 80 + cc);
       else if (!un) {
@@ -408,9 +439,10 @@ __global__ __launch_bounds__(256) void assemble_xin_kernel(const float* __restri
 }
 
 int assemble_xin(const float* x, const float* mu, const float* spks, const float* cond, float* xin, int B, int G, int S,
-                 int L, long rows2, hipStream_t st) {
+                 int L, long rows2, hipStream_t st, const int* uoff, const int* row_sample, const unsigned char* rowmask) {
+  if (uoff && (!row_sample || !rowmask)) return fail(JV_ERR_ARG, "assemble_xin: the compact geometry needs the row tables");
   hipLaunchKernelGGL(assemble_xin_kernel, dim3((unsigned)cdivl(rows2 * 80, 256)), dim3(256), 0, st, x, mu, spks, cond, xin,
-                     B, G, S, L, rows2);
+                     B, G, S, L, rows2, uoff, row_sample, rowmask);
   JV_HIP(hipGetLastError());
   return JV_OK;
 }
@@ -468,17 +500,21 @@ int time_sinusoid(const float* t, int t_stride, float* out, int B, hipStream_t s
 // ---- Euler step with classifier-free guidance: x += dt * ((1+r) d_cond - r d_uncond) ----------------------
 // d holds 2B utterances (geometry G,S); step scalars come from a device table so the loop never syncs.
 __global__ __launch_bounds__(256) void euler_cfg_kernel(float* __restrict__ x, const float* __restrict__ d, int B, int G, int S,
-                                                        int L, const float* __restrict__ dt_table, int step, float rate) {
+                                                        int L, const float* __restrict__ dt_table, int step, float rate,
+                                                        const int* __restrict__ uoff, const int* __restrict__ lens) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // f32x4 index over B*L*20
   const long per_b = (long)L * 20;
   if (idx >= per_b * B) return;
   const int b = (int)(idx / per_b);
   const long rem = idx - (long)b * per_b;
-  const long r = (long)G + (long)b * S + rem / 20;
+  const long t = rem / 20;
+  if (uoff && t >= lens[b]) return;      // compact geometry: the rows behind an utterance's frames are the next utterance's
+  const long r = uoff ? (long)uoff[b] + t : (long)G + (long)b * S + t;
+  const long ru = uoff ? (long)uoff[b + B] + t : r + (long)B * S;      // the unconditional twin's row
   const int cc = (int)(rem % 20) * 4;
   const float dt = dt_table[step];
   const f32x4 dc = *reinterpret_cast<const f32x4*>(d + r * 80 + cc);
-  const f32x4 du = *reinterpret_cast<const f32x4*>(d + (r + (long)B * S) * 80 + cc);
+  const f32x4 du = *reinterpret_cast<const f32x4*>(d + ru * 80 + cc);
   f32x4 xv = *reinterpret_cast<f32x4*>(x + r * 80 + cc);
   const f32x4 g = (1.0f + rate) * dc - rate * du;
   xv = xv + dt * g;
@@ -486,9 +522,10 @@ __global__ __launch_bounds__(256) void euler_cfg_kernel(float* __restrict__ x, c
 }
 
 int euler_cfg(float* x, const float* d, int B, int G, int S, int L, const float* dt_table, int step, float rate,
-              hipStream_t st) {
+              hipStream_t st, const int* uoff, const int* lens) {
+  if (uoff && !lens) return fail(JV_ERR_ARG, "euler_cfg: the compact geometry needs the lengths");
   hipLaunchKernelGGL(euler_cfg_kernel, dim3((unsigned)cdivl((long)B * L * 20, 256)), dim3(256), 0, st, x, d, B, G, S, L,
-                     dt_table, step, rate);
+                     dt_table, step, rate, uoff, lens);
   JV_HIP(hipGetLastError());
   return JV_OK;
 }

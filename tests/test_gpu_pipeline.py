@@ -377,7 +377,8 @@ def test_fused_block_equals_separate_launches(monkeypatch):
 def test_ff_stagger_equals_lockstep(monkeypatch):
     """rowblock_kernel's staggered feed-forward (waves 0..3 half a hidden chunk ahead of waves 4..7, so that one half's GELU
     pass runs under the other half's MFMAs; three barriers per chunk, each half's weight fragments in its own order) against
-    the schedule with every wave in the same phase (JV_NO_FF_STAGGER=1): the same sums in the same K order -- the mels must
+    the default schedule with every wave in the same phase (the staggered one is opt-in, JV_FF_STAGGER=1: it measured
+    slower, rowblock.hip): the same sums in the same K order -- the mels must
     be equal bit for bit, at tile heights 5 (32 utterances), 2 (ragged 8: the q | k | v split regime, rowblock without phase C)
     and 4 (ragged 20, last workgroup partly past the end)"""
     import jyutvoice_amd
@@ -392,9 +393,9 @@ def test_ff_stagger_equals_lockstep(monkeypatch):
         tts.load_state_dict(sd)
         return [tts.synthesise(*[b[k] for k in keys], None, n_timesteps=2, batched=True)["mel"].cpu() for b in cases]
 
-    stag = run()
-    monkeypatch.setenv("JV_NO_FF_STAGGER", "1")
     lock = run()
+    monkeypatch.setenv("JV_FF_STAGGER", "1")
+    stag = run()
     for a, b in zip(stag, lock):
         assert torch.isfinite(a).all()
         assert torch.equal(a, b), float((a - b).abs().max())
