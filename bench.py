@@ -38,19 +38,22 @@ HBM_PEAK_GBS = 8000.0
 def pmc_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from a committed PMC pass (tools/profile.sh: rocprofv3 --pmc FETCH_SIZE, doubled as
     MI355X_MICROARCH.md prescribes for gfx950, and --pmc WRITE_SIZE; counters cannot be read from inside this process).
-    Quoted only for the workload those passes ran (the default C3 shape) AND only when the file was measured on this very
+    Quoted only for the shape those passes ran (the default C3 shape, or BASELINE.json configs[1] = --workload c2 --batch 8
+    --tokens 256 from profiles/rNN_pmc_traffic_c2.json) AND only when the file was measured on this very
     build: profiles/rNN_pmc_traffic.json carries the hash of the kernel sources (jyutvoice_amd.build.source_hash) and a
     kernel edited since makes `traffic` null instead of silently stale."""
     import glob
 
     from jyutvoice_amd.build import source_hash
-    if (args.batch, args.tokens, args.timesteps) != (32, 150, 10) or args.strong:
-        return {"traffic_note": "PMC passes exist for the default C3 shape only"}
+    if args.strong or args.ragged:
+        return {"traffic_note": "PMC passes exist for the equal-length weak-scaling shapes only"}
+    shape = {"workload": args.workload, "batch": args.batch, "tokens": args.tokens, "timesteps": args.timesteps}
     here, want = os.path.dirname(os.path.abspath(__file__)), source_hash()
-    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_traffic*.json")), reverse=True):
         with open(path) as fh:
             d = json.load(fh)
-        if d.get("csrc_sha16") != want:
+        # (a file without a shape is the default C3 pass; profiles/rNN_pmc_traffic_c2.json is BASELINE.json configs[1])
+        if d.get("csrc_sha16") != want or d.get("shape", {"workload": "c3", "batch": 32, "tokens": 150, "timesteps": 10}) != shape:
             continue
         k = d["kernels"].get(kernel)
         if not k or "fetch_bytes" not in k or "write_bytes" not in k:
@@ -406,7 +409,7 @@ def main():
             # once, elementwise fused = 0) + 29.5 MB of weights per estimator call; time = HIP events over every launch of the
             # stack (resnets, down / up / final convolutions, final projection, their LayerNorm passes) in the profiled step.
             calls = n_steps * prof_steps
-            cs_bytes = calls * (96064.0 * 2 * B * T + 29.5e6)
+            cs_bytes = calls * (96064.0 * 2 * (valid_frames if args.ragged else B * T) + 29.5e6)
             gbs = cs_bytes / (cs["ms"] * 1e-3) / 1e9
             out["conv_stack"] = {"bound": "hbm (as the north star prices it; the kernels themselves are matrix-pipe bound, DESIGN.md 5)",
                                  "alg_bytes_per_pass": round(cs_bytes / prof_steps), "ms_per_pass": round(cs["ms"] / prof_steps, 3),

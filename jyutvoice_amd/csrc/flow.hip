@@ -287,8 +287,12 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   // `follow` / `followed`: the transformer block whose norm1 reads this convolution's output (a resnet's second
   // convolution, in place in the trunk): on the W-direct row-owning kernel its LayerNorm planes are written by the
   // convolution's own epilogue (RowConvArgs::ln2_out) and *followed is set; every other route leaves it to the caller
-  auto conv3 = [&](ConvGemmArgs& a, const GemmW& m, const BtbW* follow = nullptr, bool* followed = nullptr) -> int {
+  // `rn` / `res_done`: the resnet whose block1 this is -- on the W-direct row-owning kernel its 1 x 1 res_conv (which reads the
+  // same rows) rides along as a fourth fragment step per chunk and lands in w.res (RowConvArgs::res_out); *res_done says so
+  auto conv3 = [&](ConvGemmArgs& a, const GemmW& m, const BtbW* follow = nullptr, bool* followed = nullptr, const ResnetW* rn = nullptr,
+                   bool* res_done = nullptr) -> int {
     if (followed) *followed = false;
+    if (res_done) *res_done = false;
     if (splittable(a) && a.N == 256 && !a.res2) {
       // split-K tiles: the reduce kernel's tail writes the following norm1 too (fp32 rows into w.ln, what the split-K
       // blocks read), as it does between the blocks of a stage
@@ -309,6 +313,11 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     r.rowvec = a.rowvec; r.rowvec_ld = a.rowvec_ld; r.res = a.res1; r.ldr = a.ldr1;
     r.amax_out = a.amax_out; r.row_mask = w.rowmask;
     r.alg_rows = a.alg_rows;
+    if (rn && res_done && !c.no_res_fold && rn->wf4 && rn->res.colscale && rn->res.Cin == a.Cin && rowconv_w_direct(r)) {
+      r.Wf = rn->wf4; r.wf_plane = 256L * 4 * a.Cin;
+      r.res_out = w.res; r.res_cs = rn->res.colscale; r.res_bias = rn->res.bias;
+      *res_done = true;
+    }
     if (follow && followed && !c.no_ln_fold && a.out == w.h && a.ldo == 256 && follow->qkv.w2 && follow->qkv.a_scale > 0.f &&
         rowconv_w_direct(r)) {
       r.ln2_out = reinterpret_cast<unsigned short*>(w.ln); r.ln2_plane = (long)w.rows_alloc * 256;
@@ -340,11 +349,14 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     a.rowvec = w.temb + i * 256; a.row_sample = w.row_sample; a.rowvec_ld = g.temb_pre ? 0 : EST_NRES * 256;      // (0: one embedding for all rows)
     h3m(a, r.block1);
     track(a);      // -> h2
-    JV_TRY(conv3(a, r.block1));
-    a = base_args(g, in, ldin, r.res, w.res, 256);
-    a.rowmask_in = w.rowmask;
-    h3m(a, r.res);
-    JV_TRY(conv_gemm(a, 1, st));
+    bool res_done = false;
+    JV_TRY(conv3(a, r.block1, nullptr, nullptr, &r, &res_done));
+    if (!res_done) {      // (the tile kernels' route, the first resnet -- its input has no measured bound --, JV_NO_RES_FOLD=1)
+      a = base_args(g, in, ldin, r.res, w.res, 256);
+      a.rowmask_in = w.rowmask;
+      h3m(a, r.res);
+      JV_TRY(conv_gemm(a, 1, st));
+    }
     a = base_args(g, w.h2, 256, r.block2, out, ldo);
     causal3(a);
     a.ln = 1; a.ln_g = r.ln2.g; a.ln_b = r.ln2.b; a.ln_eps = 1e-5f; a.act = ACT_MISH;

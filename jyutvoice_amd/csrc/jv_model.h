@@ -140,6 +140,7 @@ struct Context {
   bool no_ffn_fuse = false;      // JV_NO_FFN_FUSE=1: ff.net.0 and ff.net.2 as two launches (the path rowffn_kernel is checked against)
   bool no_temb_pre = false;      // JV_NO_TEMB_PRE=1: the timestep embedding inside every Euler step instead of once per solve (flow.hip cfm_solve)
   bool no_ln_fold = false;       // JV_NO_LN_FOLD=1: a stage's first norm1 as its own launch (layernorm256_planes) instead of in the resnet's last convolution
+  bool no_res_fold = false;      // JV_NO_RES_FOLD=1: a resnet's 1 x 1 res_conv as a tile-kernel launch of its own instead of inside block1's row-owning launch
   bool no_compact = false;       // JV_NO_COMPACT=1: ragged batches keep the uniform row geometry (every utterance padded to the longest; flow.hip cfm_solve)
   bool no_qkv_split = false;     // JV_NO_QKV_SPLIT=1: q|k|v stays inside the fused block launch at every batch size (flow.hip `qkv_split`)
   bool no_block_fuse = false;    // JV_NO_BLOCK_FUSE=1: to_out / feed-forward / next q|k|v as three launches (the path rowblock_kernel is checked against)

@@ -611,11 +611,13 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
       load_w(par_tag, nttag);
       __builtin_amdgcn_sched_barrier(0);
     };
-    rg_f32x4 (&ac)[RT][2] = (j == 3) ? accr : acc;      // (j is a compile-time constant: no selection at run time)
-    block(std::integral_constant<int, 0>{}, ac);
-    if (j == 1 && c + 2 < NCH) rg_wait_vmcnt<NWL + NI>(); else rg_wait_vmcnt<NWL>();
-    landed_w(bq[par][1][0], bq[par][1][1], bq[par ^ 1][0][0], bq[par ^ 1][0][1]);
-    block(std::integral_constant<int, 1>{}, ac);
+    auto blocks = [&](rg_f32x4 (&ac)[RT][2]) {
+      block(std::integral_constant<int, 0>{}, ac);
+      if (j == 1 && c + 2 < NCH) rg_wait_vmcnt<NWL + NI>(); else rg_wait_vmcnt<NWL>();
+      landed_w(bq[par][1][0], bq[par][1][1], bq[par ^ 1][0][0], bq[par ^ 1][0][1]);
+      block(std::integral_constant<int, 1>{}, ac);
+    };
+    if constexpr (j == 3) blocks(accr); else blocks(acc);      // (res_conv's step: the second accumulator)
     advance_w();
     if (j == 0 && c + 2 < NCH) load_A(c + 2);      // behind this step's weight loads (the wait counts above rely on it)
   };

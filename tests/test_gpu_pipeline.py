@@ -454,6 +454,33 @@ def test_ln_fold_matches_separate_norm(monkeypatch):
         assert float((f - s).abs().max()) <= 2e-5
 
 
+def test_res_fold_matches_separate_launch(monkeypatch):
+    """A resnet's 1 x 1 res_conv (decoder.py:110-115: output = block2(h) + res_conv(x * mask)) rides in block1's row-owning launch
+    as a fourth fragment step per 32-channel chunk (RowConvArgs::res_out, rowconv_wd_kernel<RT, true>) instead of running as a
+    64 x 64 tile-kernel launch of its own (JV_NO_RES_FOLD=1).  Same operands and scales; the tile kernel multiplies with
+    32x32x16 MFMAs, the row-owning one with 16x16x32 (another summation order inside a product), so the two agree to the
+    cross-regime bound of 2e-5 -- at tile heights 5 (32 utterances) and 2 (ragged 8), compact and uniform geometry"""
+    import jyutvoice_amd
+    from jyutvoice_amd import synth
+    sd = synth.tts_state_dict(fixed_duration=1.5)
+    keys = ("x", "x_lengths", "lang", "tone", "word_pos", "syllable_pos", "spk_embed")
+    cases = [synth.batch(32, 150), synth.batch(8, 150, first_index=40, lengths=[150 - 11 * i for i in range(8)]),
+             synth.batch(20, 131, first_index=7, lengths=[131 - 3 * i for i in range(20)])]
+
+    def run():
+        tts, _ = jyutvoice_amd.build_default("cuda:0")
+        tts.load_state_dict(sd)
+        return [tts.synthesise(*[b[k] for k in keys], None, n_timesteps=2, batched=True)["mel"].cpu() for b in cases]
+
+    folded = run()
+    monkeypatch.setenv("JV_NO_RES_FOLD", "1")
+    separate = run()
+    for f, s in zip(folded, separate):
+        assert torch.isfinite(f).all()
+        assert float((f - s).abs().max()) <= 2e-5
+        assert not torch.equal(f, s)      # (the two routes are different code: identical bits would mean the switch does nothing)
+
+
 def test_timestep_embeddings_once_per_solve(monkeypatch):
     """cfm_solve computes the timestep embedding of every Euler step ahead of the loop (three GEMMs of n_timesteps rows) and
     each step copies its row into place; JV_NO_TEMB_PRE=1 computes it inside every step for all 2B (identical) rows, as the

@@ -17,15 +17,15 @@ def short(name):
     if m:
         epi = {"0": "", "1": ",gelu", "2": ",res", "3": ",res,ln", "4": ",qkv"}.get(m.group(2), "")
         return f"rowgemm_h3<{16 * int(m.group(1))}x256{epi}>"
-    m = re.search(r"rowblock_kernel<(\d+), (true|false|0|1)>", name)
+    m = re.search(r"rowblock_kernel<(\d+), (true|false|0|1)(?:, (?:true|false|0|1))?>", name)      # (<RT, QKV, STAG>)
     if m:
         return f"rowblock_h3<{16 * int(m.group(1))}x256{',qkv' if m.group(2) in ('true', '1') else ''}>"
     m = re.search(r"rowffn_kernel<(\d+)>", name)
     if m:
         return f"rowffn_h3<{16 * int(m.group(1))}x256>"
-    m = re.search(r"rowconv_(?:wd_)?kernel<(\d+)>", name)
+    m = re.search(r"rowconv_(?:wd_)?kernel<(\d+)(?:, (true|false|0|1))?>", name)      # (<RT, RES>: res_conv folded in)
     if m:
-        return f"rowconv_h3<{16 * int(m.group(1))}x256,k3>"
+        return f"rowconv_h3<{16 * int(m.group(1))}x256,k3{'+res' if m.group(2) in ('true', '1') else ''}>"
     m = re.search(r"attn64_s_kernel<(\d), \d+(?:, \d+)?>", name)
     if m:
         return f"attn64_s<{64 * int(m.group(1))} q>"
@@ -105,7 +105,12 @@ if traffic:   # per-launch HBM bytes by kernel, read back by bench.py for roofli
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from jyutvoice_amd.build import source_hash
     with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
+        extra = os.environ.get("JV_PROFILE_ARGS", "").split()      # e.g. --workload c2 --batch 8 --tokens 256 (tools/profile.sh)
+        def arg(name, default):
+            return extra[extra.index(name) + 1] if name in extra else default
         json.dump({"csrc_sha16": source_hash(),      # bench.py quotes these figures only for the build they were measured on
+                   "shape": {"workload": arg("--workload", "c3"), "batch": int(arg("--batch", 32)), "tokens": int(arg("--tokens", 150)),
+                             "timesteps": int(arg("--timesteps", 10))},
                    "source": f"tools/profile.sh {os.path.basename(out)}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE, "
-                             "separate passes over bench.py --steps 1, bytes per launch",
+                             f"separate passes over bench.py --steps 1 {' '.join(extra)}, bytes per launch",
                    "kernels": traffic}, fh, indent=1, sort_keys=True)
