@@ -138,6 +138,7 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   c.no_temb_pre = getenv("JV_NO_TEMB_PRE") != nullptr;
   c.no_attn_planes = getenv("JV_NO_ATTN_PLANES") != nullptr;
   c.no_hiftconv = getenv("JV_NO_HIFTCONV") != nullptr;
+  c.no_hift_pair = getenv("JV_NO_HIFT_PAIR") != nullptr;
   c.attn_rows = getenv("JV_ATTN_ROWS") != nullptr;
   c.attn_single = getenv("JV_NO_ATTN_SINGLE") == nullptr;
   c.max_frames = max_frames;

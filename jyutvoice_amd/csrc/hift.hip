@@ -11,12 +11,14 @@
 // Snake / LeakyReLU run in the conv kernel's prologue, bias / residual / x+si fusion / MRF mean in its epilogue.
 #include "../../include/jyutvoice_hip.h"
 #include "hiftconv_kernel.h"
+#include "hiftpair_kernel.h"
 #include "jv_model.h"
 #include "jv_ops.h"
 
 namespace jv {
 
 int hiftconv(const HiftConvArgs& a, int C, hipStream_t st);      // hiftconv.hip
+int hiftpair(const HiftPairArgs& a, int C, hipStream_t st);
 
 int f0_head(const float* h, const float* w, const float* bias, float* f0, int B, int T, int G, int S, hipStream_t st);
 int sine_source(const float* f0, const float* phase, const float* noise, const float* lin_w, const float* lin_b, float* frac,
@@ -169,9 +171,36 @@ void h3_measured(ConvGemmArgs& a, const GemmW& w, const float* am_in, float extr
 // am_*: the amax slots of cur, r, tmp and dst (HiftWs::amax); h3: fp16x3 allowed (not exact-range mode)
 int resblock(const ResBlockW& rb, const HGeo& g, int lvl, int C, long rows, long alloc, const unsigned char* mask, const float* cur,
              float* r, float* tmp, float* dst, const float* extra_res, float scale, int accumulate, float* am_cur, float* am_r,
-             float* am_tmp, float* am_dst, bool h3, bool rowconv, hipStream_t st) {
+             float* am_tmp, float* am_dst, bool h3, bool rowconv, bool pair, hipStream_t st) {
   const int dils[3] = {1, 3, 5};
   const float* in = cur;
+  // The pair of convolutions of each dilation in ONE launch (hiftpair_kernel.h) at 64 / 128 channels.  A workgroup reads its
+  // neighbours' rows as halo, so a pair never writes the buffer it reads: cur -> r -> tmp -> dst (the unfused form's
+  // intermediate buffer is free), each buffer with its own bound slots.
+  bool all_pair = pair && rowconv && h3 && (C == 64 || C == 128);
+  for (int j = 0; j < 3; ++j) all_pair = all_pair && rb.wfp[j] && rb.e1[j] > 0.f && rb.e2[j] > 0.f && rb.l1max[j] > 0.f;
+  if (all_pair) {
+    float* const bufs[3] = {r, tmp, dst};
+    float* const ams[3] = {am_r, am_tmp, am_dst};
+    float* am_in = am_cur;
+    for (int j = 0; j < 3; ++j) {
+      const bool last = j == 2;
+      HiftPairArgs a{};
+      a.A = in; a.a_rows = alloc; a.M = (int)rows; a.ntaps = rb.k; a.dil = dils[j]; a.rowmask = mask;
+      a.alpha1 = rb.a1[j]; a.alpha2 = rb.a2[j];
+      a.Wf = rb.wfp[j]; a.wf_plane = (long)C * 2 * rb.k * C;
+      a.cs1 = rb.c1[j].colscale; a.b1 = rb.c1[j].bias; a.cs2 = rb.c2[j].colscale; a.b2 = rb.c2[j].bias;
+      a.amax_in = am_in; a.e1 = rb.e1[j]; a.e2 = rb.e2[j]; a.l1max = rb.l1max[j]; a.b1max = rb.b1max[j];
+      a.slot_G = g.G[lvl]; a.slot_S = g.S[lvl]; a.slot_nb = g.B;
+      a.out = bufs[j]; a.res2 = last ? extra_res : nullptr; a.out_scale = last ? scale : 1.f; a.accumulate = last ? accumulate : 0;
+      a.amax_out = ams[j];
+      a.alg_rows = (long)g.B * g.L[lvl];
+      JV_TRY(hiftpair(a, C, st));
+      in = bufs[j];
+      am_in = ams[j];
+    }
+    return JV_OK;
+  }
   // the row-owning form (hiftconv_kernel.h): the whole Snake'd window in LDS, weights in fragment order
   auto rc = [&](const GemmW& w, const float* A, const float* alpha, float extra, float* am_in, int tap_row0, int dil, float* out,
                 const float* res1, const float* res2, float out_scale, int acc, float* am_out) -> int {
@@ -290,13 +319,13 @@ int hift_decode(Context& c, const float* mel, const float* s, const int* lens, i
       amax_geo(a, g, l, w.mask[l]);
       JV_TRY(conv_gemm(a, 1, st));
       JV_TRY(resblock(h.src_rb[i], g, l, C, g.rows[l], g.alloc[l], w.mask[l], w.si[i], w.r[i], w.tmp[i], w.xs[i], w.x[i], 1.f, 0,
-                      am(HiftWs::A_SI + i), am(HiftWs::A_R + i), am(HiftWs::A_TMP + i), am(HiftWs::A_XS + i), h3, !c.no_hiftconv, st));
+                      am(HiftWs::A_SI + i), am(HiftWs::A_R + i), am(HiftWs::A_TMP + i), am(HiftWs::A_XS + i), h3, !c.no_hiftconv, !c.no_hift_pair, st));
     }
     // x = xs now holds x_up + si ; MRF: mean of the three ResBlocks, accumulated into w.x[i]
     for (int j = 0; j < 3; ++j)
       JV_TRY(resblock(h.rb[3 * i + j], g, l, C, g.rows[l], g.alloc[l], w.mask[l], w.xs[i], w.r[i], w.tmp[i], w.x[i], nullptr,
                       1.f / 3.f, j > 0 ? 1 : 0, am(HiftWs::A_XS + i), am(HiftWs::A_R + i), am(HiftWs::A_TMP + i),
-                      am(HiftWs::A_X + i), h3, !c.no_hiftconv, st));
+                      am(HiftWs::A_X + i), h3, !c.no_hiftconv, !c.no_hift_pair, st));
     prev = w.x[i];
     am_prev = am(HiftWs::A_X + i);
     prevC = C;

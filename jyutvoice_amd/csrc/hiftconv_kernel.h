@@ -164,7 +164,10 @@ __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftconv_kernel(const H
     // four rows in flight per thread and pass.  (All 12 - 17 of a thread's rows at once measured SLOWER on the same box: the
     // vocoder stage 32.2 ms against 24.6 -- the loop below is then one 8 000-line unrolled body, and two co-resident workgroups
     // hide each other's latency anyway.)
-    constexpr int U = 4;
+#ifndef JV_HC_U
+#define JV_HC_U 4
+#endif
+    constexpr int U = JV_HC_U;
     for (int rb = r0; rb < WR; rb += U * RPI) {
       rg_f32x4 x[U];
       float sc[U];

@@ -94,6 +94,10 @@ struct ResBlockW {
   const float* a1[3];
   const float* a2[3];
   float e1[3] = {}, e2[3] = {};   // max_c 1 / (alpha_c + 1e-9): what Snake can add to |x| (fp16x3 with a measured bound); 0 = n/a
+  // the pair in one launch (hiftpair_kernel.h): both convolutions' fragments as one stream (c1's steps, then c2's; plane stride
+  // C * 2 k C halves), and the load-time half of the intermediate's bound: c1's largest row L1 norm and largest |bias|
+  const unsigned short* wfp[3] = {};
+  float l1max[3] = {}, b1max[3] = {};
   int k = 0;
 };
 struct HiftW {
@@ -148,6 +152,7 @@ struct Context {
   bool attn_single = true;       // attention_s.hip for whole-utterance attention (one wave per SIMD, software-pipelined); JV_NO_ATTN_SINGLE=1: attention_pl.hip
   bool attn_rows = false;        // JV_ATTN_ROWS=1: the estimator's attention on attention_r.hip (one workgroup per head, 80 queries per wave; measured
                                  // 66.6 us against attention_pl.hip's 60.0 at 32 x 300 frames: kept as a tested alternative)
+  bool no_hift_pair = false;     // JV_NO_HIFT_PAIR=1: a ResBlock's two convolutions as two hiftconv launches (the path hiftpair_kernel is checked against)
   bool no_hiftconv = false;      // JV_NO_HIFTCONV=1: the vocoder's ResBlock convolutions on the tile kernels (A/B aid; the path hiftconv_kernel is checked against)
   bool no_attn_planes = false;   // JV_NO_ATTN_PLANES=1: attention splits K / V itself (attention.hip) instead of taking planes
   bool no_splitk = false;        // JV_NO_SPLITK=1: no split-K at short M (A/B aid)

@@ -445,6 +445,22 @@ struct Packer {
     }
     g.wf = reinterpret_cast<const unsigned short*>(d);
   }
+  // a vocoder ResBlock's two convolutions (same k, same channel count) as one fragment stream: c1's k C / 32 steps, then c2's
+  const unsigned short* wfrag_pair(const GemmW& a, const GemmW& b) {
+    const int K = a.ntaps * a.Cin;
+    if (rc != JV_OK || !a.w2 || !b.w2 || a.N != b.N || a.Cin != a.N || b.Cin != b.N || a.ntaps != b.ntaps || a.ldw != K || b.ldw != K) return nullptr;
+    const long plane = (long)a.N * 2 * K;      // halves
+    float* d = alloc((size_t)plane + 8);
+    if (!d) return nullptr;
+    unsigned short* const wf = reinterpret_cast<unsigned short*>(d);
+    const long second = (long)(K >> 5) * (a.N >> 4) * 512;      // k-step major: the second convolution's steps start here
+    if (pack_wfrag(a.w2, (long)a.n_rows * a.ldw, a.ldw, a.N, K, wf, plane, st) != JV_OK ||
+        pack_wfrag(b.w2, (long)b.n_rows * b.ldw, b.ldw, b.N, K, wf + second, plane, st) != JV_OK) {
+      rc = JV_ERR_HIP;
+      return nullptr;
+    }
+    return wf;
+  }
   // a resnet's block1 (k = 3) and its 1 x 1 res_conv read the same rows: one fragment stream for both (ResnetW::wf4)
   void wfrag4(ResnetW& r) {
     const GemmW &b = r.block1, &q = r.res;
@@ -739,11 +755,21 @@ int finalize_model(Context& c, int model, hipStream_t st) {
         w.a1[j] = pk.ptr(q + "activations1." + S(j) + ".alpha");
         w.a2[j] = pk.ptr(q + "activations2." + S(j) + ".alpha");
         // fp16x3 with a measured input bound (hift.hip): planes + what the Snake prologue can add on top of |x|
-        (void)pk.half3(w.c1[j]);
+        const float* const l1 = pk.half3(w.c1[j]);
         (void)pk.half3(w.c2[j]);
         pk.wfrag(w.c1[j], true); pk.wfrag(w.c2[j], true);
         w.e1[j] = pk.snake_extra(w.a1[j], ch);
         w.e2[j] = pk.snake_extra(w.a2[j], ch);
+        // the pair as one launch (64 / 128 channels): one fragment stream, and the intermediate's bound from the weights
+        if ((ch == 64 || ch == 128) && w.c1[j].wf && w.c2[j].wf && l1 && w.e1[j] > 0.f && w.e2[j] > 0.f) {
+          const float l1m = pk.host_maxabs(l1, ch);
+          const float b1m = w.c1[j].bias ? pk.host_maxabs(w.c1[j].bias, ch) : 0.f;
+          if (l1m > 0.f && l1m < 1e30f && b1m == b1m && b1m < 1e30f) {
+            w.wfp[j] = pk.wfrag_pair(w.c1[j], w.c2[j]);
+            w.l1max[j] = l1m;
+            w.b1max[j] = b1m;
+          }
+        }
       }
       return w;
     };

@@ -156,6 +156,38 @@ def test_hift_ragged_batch_equals_singles(eng, hift_sd):
             assert float(wav[b, 480 * L:].abs().max()) == 0.0
 
 
+def test_hift_pair_matches_separate_launches(monkeypatch, hift_sd):
+    """A vocoder ResBlock's convolution pair in ONE launch at 64 / 128 channels (hiftpair_kernel.h: the intermediate stays in LDS,
+    its fp16x3 scale comes from a load-time bound instead of a measured maximum) against the two hiftconv launches it replaces
+    (JV_NO_HIFT_PAIR=1) and against the CPU oracle: a ragged batch (utterance boundaries and masked tails inside tiles), the same
+    injected source.  The two forms split the intermediate with different powers of two: they agree to rounding."""
+    import jyutvoice_amd
+    from oracle import hift as ohift
+    g = torch.Generator().manual_seed(123)
+    T, lens = 61, [61, 37, 50]
+    mel = torch.randn(3, 80, T, generator=g) * 1.5
+    s = torch.tanh(torch.randn(3, 1, 480 * T, generator=g) * 0.3)
+
+    def run():
+        _, hift = jyutvoice_amd.build_default("cuda:0")
+        hift.load_state_dict(hift_sd)
+        from jyutvoice_amd.runtime import get_runtime
+        return get_runtime("cuda:0").ensure(4, 512, 128).hift_decode(mel, s, torch.tensor(lens)).cpu()
+
+    fused = run()
+    monkeypatch.setenv("JV_NO_HIFT_PAIR", "1")
+    separate = run()
+    assert torch.isfinite(fused).all()
+    assert rms(fused, separate) <= 5e-6 and md(fused, separate) <= 2e-4
+    assert not torch.equal(fused, separate)      # (different code: identical bits would mean the switch does nothing)
+    w = ohift.fold_weight_norm(hift_sd)
+    for b, L in enumerate(lens):
+        want = ohift.decode(w, mel[b:b + 1, :, :L], s[b:b + 1, :, :480 * L])
+        assert rms(fused[b:b + 1, :480 * L], want) <= 5e-5, b
+        if L < T:
+            assert float(fused[b, 480 * L:].abs().max()) == 0.0
+
+
 def test_synthesise_golden(models):
     from jyutvoice_amd import synth
     tts, _ = models

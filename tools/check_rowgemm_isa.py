@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build-time check of the hand-managed register double buffer of the W-direct kernels: rowgemm_wd_kernel, rowgemm_wa_kernel,
-rowffn_kernel (rowgemm_kernel.h), rowconv_wd_kernel (rowconv_kernel.h), rowblock_kernel (rowblock_kernel.h) and hiftconv_kernel
+rowffn_kernel (rowgemm_kernel.h), rowconv_wd_kernel (rowconv_kernel.h), rowblock_kernel (rowblock_kernel.h) hiftconv_kernel and hiftpair_kernel
 (hiftconv_kernel.h: the vocoder's 72 ResBlock convolutions).
 
 The weight fragments are loaded by inline asm (global_load_dwordx4) and waited for by a counted s_waitcnt the compiler does
@@ -147,7 +147,7 @@ def main():
                 print(r.stderr[-3000:])
                 return 2
     n_k = n_bad = 0
-    for m in re.finditer(r"^(_ZN2jv\d+(rowgemm_wd_kernel|rowgemm_wa_kernel|rowffn_kernel|rowconv_wd_kernel|rowblock_kernel|hiftconv_kernel)\w+):\s*;.*?\n(.*?)\.end_amdhsa_kernel", s, re.S | re.M):
+    for m in re.finditer(r"^(_ZN2jv\d+(rowgemm_wd_kernel|rowgemm_wa_kernel|rowffn_kernel|rowconv_wd_kernel|rowblock_kernel|hiftconv_kernel|hiftpair_kernel)\w+):\s*;.*?\n(.*?)\.end_amdhsa_kernel", s, re.S | re.M):
         name, body = m.group(1), m.group(3)
         body = body.split("s_endpgm")[0]
         n_loads, bad = check_kernel(name, body)
