@@ -9,6 +9,8 @@
 // strided source convs are GEMMs over contiguous spans of the 32-column STFT row buffer (row stride 15*32 / 3*32), and
 // the gaps (>= 25 rows at every level) are the zero padding of every dilated ResBlock convolution.
 // Snake / LeakyReLU run in the conv kernel's prologue, bias / residual / x+si fusion / MRF mean in its epilogue.
+#include <algorithm>
+
 #include "../../include/jyutvoice_hip.h"
 #include "hiftconv_kernel.h"
 #include "hiftpair_kernel.h"
@@ -23,10 +25,11 @@ int hiftpair(const HiftPairArgs& a, int C, hipStream_t st);
 int f0_head(const float* h, const float* w, const float* bias, float* f0, int B, int T, int G, int S, hipStream_t st);
 int sine_source(const float* f0, const float* phase, const float* noise, const float* lin_w, const float* lin_b, float* frac,
                 float* s, int B, int T, hipStream_t st, unsigned long long seed, unsigned call);
-int stft_rows(const float* s, float* out, const int* lens, int B, int T, int G3, int S3, long rows, hipStream_t st);
-int reflect_fix(float* x, int B, int G3, int S3, int C, hipStream_t st);
+// (uoff3: optional first rows of the utterances at level 3 -- the compact geometry of ragged batches, below)
+int stft_rows(const float* s, float* out, const int* lens, int B, int T, int G3, int S3, long rows, hipStream_t st, const int* uoff3 = nullptr);
+int reflect_fix(float* x, int B, int G3, int S3, int C, hipStream_t st, const int* uoff3 = nullptr);
 int istft_head(const float* post, float* frames, float* wav, const int* lens, int B, int T, int G3, int S3, long rows,
-               hipStream_t st);
+               hipStream_t st, const int* uoff3 = nullptr);
 
 constexpr int H_G0 = 4, H_GAP0 = 4;
 constexpr int UPS[3] = {8, 5, 3};
@@ -44,6 +47,13 @@ struct HiftWs {
   float* frac = nullptr;                     // [B, 9, 480 T]
   unsigned char* mask[4] = {};
   int* lens = nullptr;
+  // COMPACT geometry of ragged batches (hift_decode): utterance b starts at mel-level row u0[b] = G0 + sum_{b' < b} (len + gap) and,
+  // every level being the mel level's rows times its factor, at row mul_l u0[b] (- 1 at level 3) of level l.  uoff[l]: those first
+  // rows (+ the first row past the batch), [max_batch + 1] ints per level; rsample[l]: the utterance of every row (row_meta), what
+  // the fp16x3 kernels index their per-utterance bounds with; h_lens / h_uoff: pinned host staging
+  int* uoff[4] = {};
+  int* rsample[4] = {};
+  int *h_lens = nullptr, *h_uoff = nullptr;
   // max |value| ever written to a buffer during the current decode, per buffer and per UTTERANCE ([A_SLOTS][max_batch]
   // device floats, zeroed at its start; conv_gemm's amax_out): the measured bound from which the consuming fp16x3
   // convolution derives its scale (amax_in) -- an utterance's waveform does not depend on its batch neighbours
@@ -79,12 +89,22 @@ int hift_ws_create(Context& c) {
   JV_TRY(F(&w->frac, (size_t)c.max_batch * 9 * 480 * c.max_frames));
   for (int l = 0; l < 4; ++l) JV_TRY(ws_alloc(c, R0 * LVL_MUL[l], reinterpret_cast<void**>(&w->mask[l])));
   JV_TRY(ws_alloc(c, sizeof(int) * c.max_batch, reinterpret_cast<void**>(&w->lens)));
+  for (int l = 0; l < 4; ++l) {
+    JV_TRY(ws_alloc(c, sizeof(int) * (c.max_batch + 1), reinterpret_cast<void**>(&w->uoff[l])));
+    JV_TRY(ws_alloc(c, sizeof(int) * R0 * LVL_MUL[l], reinterpret_cast<void**>(&w->rsample[l])));
+  }
+  JV_HIP(hipHostMalloc(reinterpret_cast<void**>(&w->h_lens), sizeof(int) * c.max_batch, hipHostMallocDefault));
+  JV_HIP(hipHostMalloc(reinterpret_cast<void**>(&w->h_uoff), sizeof(int) * 4 * (c.max_batch + 1), hipHostMallocDefault));
   w->amax_stride = c.max_batch;
   JV_TRY(ws_alloc(c, sizeof(float) * HiftWs::A_SLOTS * c.max_batch, reinterpret_cast<void**>(&w->amax)));
   return JV_OK;
 }
 
 void hift_ws_destroy(Context& c) {
+  if (c.hws) {
+    if (c.hws->h_lens) (void)hipHostFree(c.hws->h_lens);
+    if (c.hws->h_uoff) (void)hipHostFree(c.hws->h_uoff);
+  }
   delete c.hws;
   c.hws = nullptr;
 }
@@ -96,6 +116,9 @@ struct HGeo {
   long rows[4];      // rows computed at each level
   long alloc[4];     // rows readable at each level
   int G[4], S[4], L[4];
+  const int* uoff[4] = {nullptr, nullptr, nullptr, nullptr};      // compact geometry: first rows per level (device); null: uniform
+  const int* rsample[4] = {nullptr, nullptr, nullptr, nullptr};   // ... and the row -> utterance tables
+  long frames = 0;                                                // profiler: real mel frames of the call (0: B * T)
 };
 
 HGeo make_geo(const Context& c, int B, int T) {
@@ -146,18 +169,20 @@ int prepare_masks(Context& c, const HGeo& g, const int* lens, hipStream_t st) {
   if (lens) JV_HIP(hipMemcpyAsync(w.lens, lens, sizeof(int) * g.B, hipMemcpyDeviceToDevice, st));
   else JV_TRY(fill_int(w.lens, g.T, g.B, st));
   for (int l = 0; l < 4; ++l)
-    JV_TRY(row_meta(w.mask[l], nullptr, w.lens, g.B, 1, g.G[l], g.S[l], g.L[l], g.alloc[l], LVL_MUL[l], l == 3 ? 1 : 0, st));
+    JV_TRY(row_meta(w.mask[l], g.uoff[l] ? w.rsample[l] : nullptr, w.lens, g.B, 1, g.G[l], g.S[l], g.L[l], g.alloc[l], LVL_MUL[l],
+                    l == 3 ? 1 : 0, st, g.uoff[l]));
   return JV_OK;
 }
 
 int mel_to_rows(Context& c, const HGeo& g, const float* mel, hipStream_t st) {
-  return cf_to_rows(mel, 80L * g.T, g.T, g.B, 80, g.T, c.hws->mel, 96, 0, H_G0, g.S0, 1.f, c.hws->lens, st);
+  return cf_to_rows(mel, 80L * g.T, g.T, g.B, 80, g.T, c.hws->mel, 96, 0, H_G0, g.S0, 1.f, c.hws->lens, st, g.uoff[0]);
 }
 
 // the per-utterance slot geometry of the rows at `lvl` (ConvGemmArgs::amax_G/S/nb); rows the level's mask marks as
 // padding are not tracked
 void amax_geo(ConvGemmArgs& a, const HGeo& g, int lvl, const unsigned char* mask) {
   a.amax_G = g.G[lvl]; a.amax_S = g.S[lvl]; a.amax_nb = g.B; a.amax_mask = mask;
+  a.amax_rows = g.rsample[lvl];      // compact geometry: a row's utterance by table
 }
 
 // fp16x3 on a convolution whose input bound is measured (am_in) and whose prologue adds at most `extra` to |x|
@@ -191,10 +216,10 @@ int resblock(const ResBlockW& rb, const HGeo& g, int lvl, int C, long rows, long
       a.Wf = rb.wfp[j]; a.wf_plane = (long)C * 2 * rb.k * C;
       a.cs1 = rb.c1[j].colscale; a.b1 = rb.c1[j].bias; a.cs2 = rb.c2[j].colscale; a.b2 = rb.c2[j].bias;
       a.amax_in = am_in; a.e1 = rb.e1[j]; a.e2 = rb.e2[j]; a.l1max = rb.l1max[j]; a.b1max = rb.b1max[j];
-      a.slot_G = g.G[lvl]; a.slot_S = g.S[lvl]; a.slot_nb = g.B;
+      a.slot_G = g.G[lvl]; a.slot_S = g.S[lvl]; a.slot_nb = g.B; a.slot_map = g.rsample[lvl];
       a.out = bufs[j]; a.res2 = last ? extra_res : nullptr; a.out_scale = last ? scale : 1.f; a.accumulate = last ? accumulate : 0;
       a.amax_out = ams[j];
-      a.alg_rows = (long)g.B * g.L[lvl];
+      a.alg_rows = g.frames ? g.frames * LVL_MUL[lvl] : (long)g.B * g.L[lvl];
       JV_TRY(hiftpair(a, C, st));
       in = bufs[j];
       am_in = ams[j];
@@ -207,10 +232,10 @@ int resblock(const ResBlockW& rb, const HGeo& g, int lvl, int C, long rows, long
     HiftConvArgs a{};
     a.A = A; a.a_rows = alloc; a.M = (int)rows; a.ntaps = w.ntaps; a.dil = dil; a.tap_row0 = tap_row0; a.rowmask_in = mask;
     a.alpha = alpha; a.Wf = w.wf; a.wf_plane = (long)w.N * w.ntaps * w.Cin; a.colscale = w.colscale; a.bias = w.bias;
-    a.amax_in = am_in; a.a_extra = extra; a.slot_G = g.G[lvl]; a.slot_S = g.S[lvl]; a.slot_nb = g.B;
+    a.amax_in = am_in; a.a_extra = extra; a.slot_G = g.G[lvl]; a.slot_S = g.S[lvl]; a.slot_nb = g.B; a.slot_map = g.rsample[lvl];
     a.out = out; a.res1 = res1; a.res2 = res2; a.out_scale = out_scale; a.accumulate = acc;
     a.amax_out = am_out; a.amax_mask = mask;
-    a.alg_rows = (long)g.B * g.L[lvl];
+    a.alg_rows = g.frames ? g.frames * LVL_MUL[lvl] : (long)g.B * g.L[lvl];
     return hiftconv(a, C, st);
   };
   for (int j = 0; j < 3; ++j) {
@@ -279,11 +304,37 @@ int hift_decode(Context& c, const float* mel, const float* s, const int* lens, i
   JV_TRY(check(c, B, T));
   HiftWs& w = *c.hws;
   const HiftW& h = c.hift;
-  const HGeo g = make_geo(c, B, T);
+  HGeo g = make_geo(c, B, T);
+  // Ragged batch: the COMPACT geometry (HiftWs::uoff) when it saves at least 8 % of the rows -- every level's rows are the mel
+  // level's times a factor, so laying the utterances end to end at the mel level lays them end to end everywhere.  The lengths
+  // come down once (B ints, one synchronisation per decode); every per-row sum is the uniform geometry's: the same bits.
+  if (lens && B > 1 && !c.no_compact) {
+    JV_HIP(hipMemcpyAsync(w.h_lens, lens, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    JV_HIP(hipStreamSynchronize(st));
+    long r = H_G0, frames = 0;
+    int* const hu = w.h_uoff;
+    for (int b = 0; b <= B; ++b) {
+      for (int l = 0; l < 4; ++l) hu[l * (B + 1) + b] = (int)(r * LVL_MUL[l]) - (l == 3 ? 1 : 0);
+      if (b < B) {
+        const int len = std::min(std::max(w.h_lens[b], 0), T);
+        r += len + H_GAP0;
+        frames += len;
+      }
+    }
+    if (r * 100 <= (H_G0 + (long)B * g.S0) * 92) {
+      for (int l = 0; l < 4; ++l) {
+        JV_HIP(hipMemcpyAsync(w.uoff[l], hu + l * (B + 1), sizeof(int) * (B + 1), hipMemcpyHostToDevice, st));      // (pinned: stays valid)
+        g.uoff[l] = w.uoff[l];
+        g.rsample[l] = w.rsample[l];
+        g.rows[l] = r * LVL_MUL[l];
+      }
+      g.frames = frames;
+    }
+  }
   JV_TRY(prepare_masks(c, g, lens, st));
   JV_TRY(mel_to_rows(c, g, mel, st));
   float* stft = w.stft_alloc + 16 * 32;
-  JV_TRY(stft_rows(s, stft, w.lens, B, T, g.G[3], g.S[3], g.alloc[3], st));
+  JV_TRY(stft_rows(s, stft, w.lens, B, T, g.G[3], g.S[3], g.alloc[3], st, g.uoff[3]));
   JV_HIP(hipMemsetAsync(w.amax, 0, sizeof(float) * HiftWs::A_SLOTS * w.amax_stride, st));
   const bool h3 = !c.exact_range;
   auto am = [&](int slot) { return w.amax + (long)slot * w.amax_stride; };
@@ -309,7 +360,7 @@ int hift_decode(Context& c, const float* mel, const float* s, const int* lens, i
       a.amax_out = h3 ? am(HiftWs::A_X + i) : nullptr;
       amax_geo(a, g, i, w.mask[i]);      // rows of the INPUT level: output row r carries the UPS[i] frames it expands to
       JV_TRY(conv_gemm(a, 1, st));
-      if (i == 2) JV_TRY(reflect_fix(w.x[i], B, g.G[3], g.S[3], C, st));
+      if (i == 2) JV_TRY(reflect_fix(w.x[i], B, g.G[3], g.S[3], C, st, g.uoff[3]));
     }
     // source branch: strided conv of the STFT rows, then a ResBlock whose last layer also adds the up-sampled trunk
     {
@@ -336,7 +387,7 @@ int hift_decode(Context& c, const float* mel, const float* s, const int* lens, i
     a.pro = PRO_LRELU; a.pro_slope = 0.01f;
     JV_TRY(conv_gemm(a, 1, st));
   }
-  return istft_head(w.post, w.frames, wav, w.lens, B, T, g.G[3], g.S[3], g.rows[3], st);
+  return istft_head(w.post, w.frames, wav, w.lens, B, T, g.G[3], g.S[3], g.rows[3], st, g.uoff[3]);
 }
 
 }  // namespace jv

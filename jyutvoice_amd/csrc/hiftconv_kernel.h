@@ -35,6 +35,7 @@ struct HiftConvArgs {
   const float* amax_in;            // per-utterance measured bound of A; scale = h3_scale_dev(amax_in[slot] + a_extra)
   float a_extra;                   // what Snake can add to |x|: max 1 / (alpha + 1e-9)
   int slot_G, slot_S, slot_nb;     // slot(row) = clamp((row - slot_G) / slot_S, 0, slot_nb - 1)
+  const int* slot_map;             // or, when set: slot(row) = slot_map[row] (the compact geometry of ragged batches: a table per level)
   float* out;                      // [rows, C]:  out = ((acc + bias) + res1 + res2) * out_scale (+ previous out)
   const float *res1, *res2;        // [rows, C] or null (either may alias out)
   float out_scale;
@@ -127,6 +128,10 @@ __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftconv_kernel(const H
 
   // ---- per-row facts: the window rows' scales (one level of unconditional loads on clamped indices: rowconv_wd_kernel) ----
   auto slot_of = [&](const long row) -> int {
+    if (p.slot_map) {      // compact geometry of ragged batches (hift.hip): by table; every caller clamps `row` to the buffer
+      const int q = p.slot_map[row];
+      return q < 0 ? 0 : (q >= p.slot_nb ? p.slot_nb - 1 : q);
+    }
     if (p.slot_S <= 0) return 0;
     const int q = (int)((row - p.slot_G) / p.slot_S);
     return q < 0 ? 0 : (q >= p.slot_nb ? p.slot_nb - 1 : q);

@@ -182,17 +182,30 @@ int sine_source(const float* f0, const float* phase, const float* noise, const f
 // ---- STFT(16, hop 4, periodic Hann, center/reflect) of s -> row buffer [479 + b*S3 + tau][32] = 9 re | 9 im | 0 ----
 // Every row of the buffer is written (zeros outside the utterance): the strided source convs read it unmasked.
 __global__ __launch_bounds__(256) void stft_rows_kernel(const float* __restrict__ s, float* __restrict__ out,
-                                                        const int* __restrict__ lens, int B, int T, int G3, int S3, long rows) {
+                                                        const int* __restrict__ lens, int B, int T, int G3, int S3, long rows,
+                                                        const int* __restrict__ uoff3) {
   const long r = (long)blockIdx.x * 256 + threadIdx.x;
   if (r >= rows) return;
   f32x4 o[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const long rel = r - G3;
+  long rel = r - G3;
+  long bl = 0, tau = 0;
+  if (uoff3) {      // compact geometry (hift.hip): utterance b starts at row uoff3[b]; the last entry is the first row past the batch
+    int lo = 0, hi = B - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (uoff3[mid] <= r) lo = mid; else hi = mid - 1;
+    }
+    bl = r < uoff3[B] ? lo : B;
+    tau = r - uoff3[lo];
+    rel = tau;      // (< 0 ahead of the first utterance)
+  } else if (rel >= 0) {
+    bl = rel / S3;      // rows past the batch exist whenever the context's capacity exceeds this call's batch:
+    tau = rel - bl * S3;
+  }
   if (rel >= 0) {
-    const long bl = rel / S3;      // rows past the batch exist whenever the context's capacity exceeds this call's batch:
     const int b = bl < B ? (int)bl : B - 1;      // never index lens[] / s with them
-    const long tau = rel - bl * S3;
     const int len = lens ? min(lens[b], T) : T;
     const long nvalid = (long)len * 480;
     if (bl < B && tau <= (long)len * 120 && nvalid > 0) {
@@ -228,20 +241,20 @@ __global__ __launch_bounds__(256) void stft_rows_kernel(const float* __restrict_
   for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(out + r * 32 + 4 * i) = o[i];
 }
 
-int stft_rows(const float* s, float* out, const int* lens, int B, int T, int G3, int S3, long rows, hipStream_t st) {
-  hipLaunchKernelGGL(stft_rows_kernel, dim3((unsigned)cdivl(rows, 256)), dim3(256), 0, st, s, out, lens, B, T, G3, S3, rows);
+int stft_rows(const float* s, float* out, const int* lens, int B, int T, int G3, int S3, long rows, hipStream_t st, const int* uoff3) {
+  hipLaunchKernelGGL(stft_rows_kernel, dim3((unsigned)cdivl(rows, 256)), dim3(256), 0, st, s, out, lens, B, T, G3, S3, rows, uoff3);
   JV_HIP(hipGetLastError());
   return JV_OK;
 }
 
 // ---- ReflectionPad1d((1,0)) after the last up-conv: row(tau=0) := row(tau=2) --------------------------------------
-__global__ void reflect_fix_kernel(float* __restrict__ x, int B, int G3, int S3, int C) {
+__global__ void reflect_fix_kernel(float* __restrict__ x, int B, int G3, int S3, int C, const int* __restrict__ uoff3) {
   const int b = blockIdx.x;
-  float* base = x + ((long)G3 + (long)b * S3) * C;
+  float* base = x + (uoff3 ? (long)uoff3[b] : (long)G3 + (long)b * S3) * C;
   for (int c = threadIdx.x; c < C; c += blockDim.x) base[c] = base[2 * C + c];
 }
-int reflect_fix(float* x, int B, int G3, int S3, int C, hipStream_t st) {
-  hipLaunchKernelGGL(reflect_fix_kernel, dim3(B), dim3(64), 0, st, x, B, G3, S3, C);
+int reflect_fix(float* x, int B, int G3, int S3, int C, hipStream_t st, const int* uoff3) {
+  hipLaunchKernelGGL(reflect_fix_kernel, dim3(B), dim3(64), 0, st, x, B, G3, S3, C, uoff3);
   JV_HIP(hipGetLastError());
   return JV_OK;
 }
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, float* __restrict__ wav,
                                                         const int* __restrict__ lens, int B, int T, int G3, int S3,
-                                                        float limit) {
+                                                        float limit, const int* __restrict__ uoff3) {
   const long n_per = (long)T * 480;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n_per * B) return;
@@ -292,7 +305,7 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
       const long tau = t_hi - i;
       const int k = (int)(n + 8 - 4 * tau);
       if (tau >= 0 && tau <= ntau && k >= 0 && k < 16) {
-        num += frames[((long)G3 + (long)b * S3 + tau) * 16 + k];
+        num += frames[((uoff3 ? (long)uoff3[b] : (long)G3 + (long)b * S3) + tau) * 16 + k];
         den += c_hann16[k] * c_hann16[k];
       }
     }
@@ -303,10 +316,10 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
 }
 
 int istft_head(const float* post, float* frames, float* wav, const int* lens, int B, int T, int G3, int S3, long rows,
-               hipStream_t st) {
+               hipStream_t st, const int* uoff3) {
   hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)cdivl(rows, 256)), dim3(256), 0, st, post, frames, rows);
   hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)cdivl((long)B * T * 480, 256)), dim3(256), 0, st, frames, wav, lens, B, T,
-                     G3, S3, 0.99f);
+                     G3, S3, 0.99f, uoff3);
   JV_HIP(hipGetLastError());
   return JV_OK;
 }

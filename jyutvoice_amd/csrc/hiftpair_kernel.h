@@ -49,6 +49,7 @@ struct HiftPairArgs {
   float e1, e2;                    // max 1 / (alpha + 1e-9) of Snake1 / Snake2
   float l1max, b1max;              // largest row L1 norm and largest |bias| of the first convolution
   int slot_G, slot_S, slot_nb;     // slot(row) = clamp((row - slot_G) / slot_S, 0, slot_nb - 1)
+  const int* slot_map;             // or, when set: slot(row) = slot_map[row] (HiftConvArgs::slot_map)
   float* out;                      // [rows, C]: out = ((acc2 + b2) + x + res2) * out_scale (+ previous out)
   const float* res2;               // [rows, C] or null
   float out_scale;
@@ -138,6 +139,10 @@ __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftpair_kernel(const H
 
   // ---- per-row facts (one level of unconditional loads on clamped indices: rowconv_wd_kernel) ----
   auto slot_of = [&](const long row) -> int {
+    if (p.slot_map) {      // compact geometry of ragged batches (hift.hip): by table; every caller clamps `row` to the buffer
+      const int q = p.slot_map[row];
+      return q < 0 ? 0 : (q >= p.slot_nb ? p.slot_nb - 1 : q);
+    }
     if (p.slot_S <= 0) return 0;
     const int q = (int)((row - p.slot_G) / p.slot_S);
     return q < 0 ? 0 : (q >= p.slot_nb ? p.slot_nb - 1 : q);

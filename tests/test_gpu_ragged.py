@@ -52,6 +52,32 @@ def test_compact_geometry_equals_uniform(monkeypatch):
         assert torch.equal(a, b), float((a - b).abs().max())
 
 
+def test_vocoder_compact_geometry_equals_uniform(monkeypatch, hift_sd):
+    """HiFT on a ragged batch: the compact geometry (every level's rows are the mel level's times a factor, so the utterances
+    lie end to end at every level: hift.hip hift_decode) against the uniform one (JV_NO_COMPACT=1) -- the waveforms are equal bit
+    for bit and zero behind each utterance's last sample"""
+    import jyutvoice_amd
+    from jyutvoice_amd.runtime import get_runtime
+    g = torch.Generator().manual_seed(5)
+    T, lens = 70, [70, 31, 70, 12, 55, 64]
+    mel = torch.randn(len(lens), 80, T, generator=g) * 1.5
+    s = torch.tanh(torch.randn(len(lens), 1, 480 * T, generator=g) * 0.3)
+
+    def run():
+        _, hift = jyutvoice_amd.build_default("cuda:0")
+        hift.load_state_dict(hift_sd)
+        return get_runtime("cuda:0").ensure(8, 512, 128).hift_decode(mel, s, torch.tensor(lens)).cpu()
+
+    compact = run()
+    monkeypatch.setenv("JV_NO_COMPACT", "1")
+    uniform = run()
+    assert torch.isfinite(compact).all()
+    assert torch.equal(compact, uniform), float((compact - uniform).abs().max())
+    for b, L in enumerate(lens):
+        if L < T:
+            assert float(compact[b, 480 * L:].abs().max()) == 0.0
+
+
 def test_ragged_fullsize_vs_oracle(hift_sd, noise):
     """32 utterances of 60 .. 150 tokens (bench.py --ragged's lengths), n = 10, encoder -> CFM -> HiFT: the shortest, a middle and
     the longest utterance against oracle.tts.synthesise / oracle.hift.decode run on each alone"""
