@@ -219,7 +219,12 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
   // High planes stay in registers (80 for five tiles), low planes go to the wave's LDS patch and come back per (tile, k-step).
   // (the next tile's global loads are issued ahead of this tile's arithmetic)
   u32x4 qh[QT][4];
-  f32x4 qraw[2][8];
+#ifndef JV_AS_QDEPTH
+#define JV_AS_QDEPTH 2      // Q tiles in flight in the prologue (tuning: -DJV_AS_QDEPTH=n).  3 measured the same and 5 SLOWER (54.1 against
+                            // 52.8 us per launch, same box): the prologue's 39 MB of Q is a bandwidth burst, not a latency chain
+#endif
+  constexpr int QD = JV_AS_QDEPTH < QT ? JV_AS_QDEPTH : QT;
+  f32x4 qraw[QD][8];
   auto fetch_q = [&](const int t, f32x4 (&r)[8]) {
     const int qi = q0 + 32 * t + r32;
     const float* qs = p.qkv + (rowbase + max(min(qi, Lq - 1), 0)) * p.ld + h * 64 + 8 * half;      // (clamped: zeroed below)
@@ -229,14 +234,15 @@ __global__ __launch_bounds__(64 * AS_NW, 1) void attn64_s_kernel(const AttnArgs 
       r[2 * s + 1] = *(const __attribute__((address_space(1))) f32x4*)(qs + 16 * s + 4);
     }
   };
-  fetch_q(0, qraw[0]);
+#pragma unroll
+  for (int t = 0; t < QD - 1; ++t) fetch_q(t, qraw[t]);
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    if (t + 1 < QT) fetch_q(t + 1, qraw[(t + 1) & 1]);
+    if (t + QD - 1 < QT) fetch_q(t + QD - 1, qraw[(t + QD - 1) % QD]);
     const float live = (q0 + 32 * t + r32) < Lq ? qsc : 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const f32x4 t0 = qraw[t & 1][2 * s], t1 = qraw[t & 1][2 * s + 1];
+      const f32x4 t0 = qraw[t % QD][2 * s], t1 = qraw[t % QD][2 * s + 1];
       u32x4 lo;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
