@@ -29,6 +29,9 @@ def short(name):
     m = re.search(r"attn64_s_kernel<(\d), \d+(?:, \d+)?>", name)
     if m:
         return f"attn64_s<{64 * int(m.group(1))} q>"
+    m = re.search(r"hiftpair_kernel<(\d+), (\d+)>", name)
+    if m:
+        return f"hiftpair_h3<{80 * int(m.group(2))}x{m.group(1)},snake>"
     m = re.search(r"hiftconv_kernel<(\d+), (\d+)>", name)
     if m:
         return f"hiftconv_h3<{80 * int(m.group(2))}x{m.group(1)},snake>"
