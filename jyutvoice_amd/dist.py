@@ -18,6 +18,31 @@ def shard_range(n_utts: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def balanced_shards(lengths, world: int, gap: int = 4) -> List[List[int]]:
+    """Length-aware shards for RAGGED global batches (SURVEY.md 8(e) "optionally length-bucketed"): with the compact row geometry
+    a rank's time follows the frames it holds, so contiguous shards of unequal utterances finish at different times.  Longest
+    first, each utterance to the rank holding the fewest rows so far (rows = frames + the gap of the row layout; ties: the
+    lower rank); indices inside a rank stay in ascending order.  Deterministic: every rank computes the same answer from the
+    same lengths.  `gather_order` restores the global order after `all_gather_mels`."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    shards: List[List[int]] = [[] for _ in range(world)]
+    load = [0] * world
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        shards[r].append(i)
+        load[r] += int(lengths[i]) + gap
+    return [sorted(s) for s in shards]
+
+
+def gather_order(shards: List[List[int]]) -> torch.Tensor:
+    """index tensor `inv` with gathered[inv] in the original utterance order, where `gathered` is what all_gather_mels returns
+    when rank r contributed the utterances shards[r] (rank-major concatenation)"""
+    flat = [i for s in shards for i in s]
+    inv = torch.empty(len(flat), dtype=torch.int64)
+    inv[torch.tensor(flat, dtype=torch.int64)] = torch.arange(len(flat), dtype=torch.int64)
+    return inv
+
+
 def all_gather_mels(mel: torch.Tensor, lengths: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """mel [b,80,T_local], lengths [b] on every rank -> (mel [sum b,80,T_max], lengths [sum b]) on every rank.
 
