@@ -65,7 +65,7 @@ int hiftpair(const HiftPairArgs& a, int C, hipStream_t st) {
   if (a.ntaps < 1 || a.ntaps > 11 || !(a.ntaps & 1) || a.dil < 1 || (a.ntaps - 1) * a.dil > 56) return fail(JV_ERR_ARG, "hiftpair: odd kernel sizes up to 11, window up to 56 rows");
   if (!(a.l1max > 0.f) || !(a.e1 > 0.f) || !(a.e2 > 0.f)) return fail(JV_ERR_ARG, "hiftpair: needs the intermediate's bound (L1 norm, Snake extras)");
   switch (C) {
-    case 64: return dyn_env("JV_HP_NG4") || getenv("JV_HP_NG4") ? hp_launch<64, 4>(a, st) : hp_launch<64, 2>(a, st);      // (NG 4: 320-row tiles, one eight-wave workgroup per CU -- tuning A/B)
+    case 64: return hp_launch<64, 2>(a, st);
     case 128: return hp_launch<128, 2>(a, st);
     default: return fail(JV_ERR_ARG, "hiftpair: 64 or 128 channels");
   }
