@@ -74,7 +74,7 @@ def kernel_peak(name: str):
         # the dense bf16 MFMA peak / 6
         return BF16_MFMA_PEAK_TFLOPS / 6.0, ("fp32 operands split into 3 bf16 planes, 6 x v_mfma_f32_32x32x16_bf16 per product, "
                                              "fp32 accumulate; peak = dense bf16 MFMA (2500) / 6")
-    if name.startswith(("conv_gemm_h3", "attn64_h3", "attn64_pl", "rowgemm_h3", "rowconv_h3", "rowffn_h3", "rowblock_h3", "hiftconv_h3", "hiftpair_h3", "attn64_r", "attn64_s")):
+    if name.startswith(("conv_gemm_h3", "attn64_h3", "attn64_pl", "rowgemm_h3", "rowconv_h3", "rowres_h3", "rowffn_h3", "rowblock_h3", "hiftconv_h3", "hiftpair_h3", "attn64_r", "attn64_s")):
         # fp16x3: three fp16 MFMA products per fp32-accurate multiply-add (fp16 and bf16 MFMA rates are equal)
         return BF16_MFMA_PEAK_TFLOPS / 3.0, ("fp32 operands scaled by an exact power of two and split into 2 fp16 planes (22 bits), "
                                              "3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; peak = dense fp16 MFMA (2500) / 3")

@@ -134,6 +134,7 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   c.no_qkv_split = getenv("JV_NO_QKV_SPLIT") != nullptr;
   c.no_compact = getenv("JV_NO_COMPACT") != nullptr;
   c.no_res_fold = getenv("JV_NO_RES_FOLD") != nullptr;
+  c.no_res_pair = getenv("JV_NO_RES_PAIR") != nullptr;
   c.no_ln_fold = getenv("JV_NO_LN_FOLD") != nullptr;
   c.no_temb_pre = getenv("JV_NO_TEMB_PRE") != nullptr;
   c.no_attn_planes = getenv("JV_NO_ATTN_PLANES") != nullptr;

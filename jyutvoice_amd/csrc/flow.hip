@@ -16,11 +16,14 @@
 #include "jv_ops.h"
 #include "rowblock_kernel.h"
 #include "rowconv_kernel.h"
+#include "rowres_kernel.h"
 
 namespace jv {
 
 int rowgemm(const RowGemmArgs& a, int epi, hipStream_t st);   // rowgemm.hip
 int rowconv(const RowConvArgs& a, hipStream_t st);
+int rowres(const RowResArgs& a, hipStream_t st);      // rowgemm.hip: a whole resnet in one launch
+bool rowres_fits(int M);
 bool rowconv_w_direct(const RowConvArgs& a);      // rowgemm.hip
 int rowffn(const RowFfnArgs& a, hipStream_t st);
 int rowblock(const RowBlockArgs& a, bool qkv, hipStream_t st);   // rowblock.hip
@@ -339,9 +342,42 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     ConvStackScope() : on(prof_on()) { if (on) prof_group("flow_conv_stack"); }
     ~ConvStackScope() { if (on) prof_group(nullptr); }
   };
+  auto res_pair_ok = [&](int i, const float* in, int ldin) {
+    const ResnetW& r = e.res[i];
+    return use_rc && !c.no_res_pair && !c.no_res_fold && g.temb_pre && slots_of(in) && in != w.xin && r.wf4 && r.block2.wf &&
+           r.h2_bound > 0.f && r.block1.colscale && r.block2.colscale && r.res.colscale && r.block1.Cin == ldin && !(ldin & 63) &&
+           rowres_fits((int)g.M);
+  };
   auto resnet = [&](int i, const float* in, int ldin, float* out, int ldo, const BtbW* follow = nullptr, bool* followed = nullptr) -> int {
     ConvStackScope scope;
     const ResnetW& r = e.res[i];
+    // The whole resnet in ONE launch (rowres_kernel.h) where every piece has its row-owning form: a trunk input with a
+    // measured bound, fragment-order weights for block1 | res_conv and for block2, the step's time embedding shared by all
+    // rows (cfm_solve), a tile height that keeps the launch in as many rounds as the two it replaces.  JV_NO_RES_PAIR=1: two.
+    // (a workgroup reads its neighbours' rows as halo, so the launch never writes the buffer it reads: the caller alternates the
+    // trunk between w.h and w.h2 -- res_pair_ok / the mid-stage loop below)
+    if (res_pair_ok(i, in, ldin) && out != in) {
+      RowResArgs a{};
+      a.A = in; a.lda = ldin; a.a_rows = g.a_rows; a.M = (int)g.M; a.Cin = ldin;
+      a.rowmask = w.rowmask;
+      a.amax_in = slots_of(in); a.slot_G = FLOW_G; a.slot_S = g.uoff ? -1 : g.S; a.slot_nb = B2; a.row_slot = w.row_sample;
+      a.Wf1 = r.wf4; a.wf1_plane = 256L * 4 * ldin;
+      a.cs1 = r.block1.colscale; a.b1 = r.block1.bias; a.ln1_g = r.ln1.g; a.ln1_b = r.ln1.b;
+      a.csr = r.res.colscale; a.br = r.res.bias;
+      a.temb = w.temb + i * 256; a.h2_bound = r.h2_bound; a.ln_eps = 1e-5f;
+      a.Wf2 = r.block2.wf; a.wf2_plane = 256L * 3 * 256;
+      a.cs2 = r.block2.colscale; a.b2 = r.block2.bias; a.ln2_g = r.ln2.g; a.ln2_b = r.ln2.b;
+      a.out = out; a.ldo = ldo;
+      a.amax_out = slots_of(out);
+      a.alg_rows = g.alg_rows ? g.alg_rows : (long)g.B2 * g.T;
+      if (followed) *followed = false;
+      if (follow && followed && !c.no_ln_fold && ldo == 256 && follow->qkv.w2 && follow->qkv.a_scale > 0.f) {
+        a.lnf_out = reinterpret_cast<unsigned short*>(w.ln); a.lnf_plane = (long)w.rows_alloc * 256;
+        a.lnf_g = follow->n1.g; a.lnf_b = follow->n1.b; a.lnf_scale = follow->qkv.a_scale;
+        *followed = true;
+      }
+      return rowres(a, st);
+    }
     ConvGemmArgs a = base_args(g, in, ldin, r.block1, w.h2, 256);
     causal3(a);
     a.ln = 1; a.ln_g = r.ln1.g; a.ln_b = r.ln1.b; a.ln_eps = 1e-5f; a.act = ACT_MISH;
@@ -619,10 +655,17 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     JV_TRY(conv3(a, e.down_conv));
   }
   // mid x12; the last block writes straight into columns [0,256) of the concat buffer
+  // (the whole-resnet launch must not write the buffer it reads: the trunk then alternates between w.h and w.h2 -- h2 is free,
+  // the launch keeps block1's output in LDS -- and an even number of mid stages brings it back to w.h; both have bound slots)
+  float* trunk = w.h;
+  const bool mid_pair = (EST_NMID % 2 == 0);
   for (int i = 1; i <= EST_NMID; ++i) {
-    JV_TRY(resnet(i, w.h, 256, w.h, 256, follow_of(e.blk[i]), &lnf));
-    JV_TRY(stage_blocks(e.blk[i], w.h, i == EST_NMID ? w.cat : w.h, i == EST_NMID ? 512 : 256, lnf));
+    float* const dst = (mid_pair && res_pair_ok(i, trunk, 256)) ? (trunk == w.h ? w.h2 : w.h) : trunk;
+    JV_TRY(resnet(i, trunk, 256, dst, 256, follow_of(e.blk[i]), &lnf));
+    trunk = dst;
+    JV_TRY(stage_blocks(e.blk[i], trunk, i == EST_NMID ? w.cat : trunk, i == EST_NMID ? 512 : 256, lnf));
   }
+  if (trunk != w.h) return fail(JV_ERR_STATE, "flow: the mid stages left the trunk in the scratch buffer");
   // up: resnet(cat[x, skip]) -> 4 blocks -> causal conv -> final block -> 1x1 projection
   JV_TRY(resnet(EST_NRES - 1, w.cat, 512, w.h, 256, follow_of(e.blk[EST_NRES - 1]), &lnf));
   JV_TRY(stage_blocks(e.blk[EST_NRES - 1], w.h, w.h, 256, lnf));

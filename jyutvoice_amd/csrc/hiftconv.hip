@@ -28,7 +28,7 @@ int hc_launch(const HiftConvArgs& a, hipStream_t st) {
   JV_HIP(hipGetLastError());
   return JV_OK;
 }
-template <int C, int NG>
+template <int C, int NG, int KT>
 int hp_launch(const HiftPairArgs& a, hipStream_t st) {
   static int raised[64] = {};      // per device: the LDS size the attribute was last raised to
   int dev = 0;
@@ -36,13 +36,13 @@ int hp_launch(const HiftPairArgs& a, hipStream_t st) {
   const int lds = hp_lds_bytes<C, NG>(a.ntaps, a.dil);
   if (lds > 160 * 1024) return fail(JV_ERR_ARG, "hiftpair: the window does not fit LDS");
   if (raised[dev & 63] < lds) {
-    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hiftpair_kernel<C, NG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hiftpair_kernel<C, NG, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     raised[dev & 63] = lds;
   }
   const bool prof = prof_on();
   if (prof) prof_begin(st);
   const int ro = hp_rows<NG>() - (a.ntaps - 1);      // output rows per workgroup
-  hipLaunchKernelGGL((hiftpair_kernel<C, NG>), dim3(cdiv(a.M, ro)), dim3(hc_threads<C, NG>()), lds, st, a);
+  hipLaunchKernelGGL((hiftpair_kernel<C, NG, KT>), dim3(cdiv(a.M, ro)), dim3(hc_threads<C, NG>()), lds, st, a);
   if (prof) {
     static const std::string name = std::string("hiftpair_h3<") + std::to_string(hp_rows<NG>()) + "x" + std::to_string(C) + ",snake>";
     const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M);
@@ -62,12 +62,16 @@ int hiftpair(const HiftPairArgs& a, int C, hipStream_t st) {
   if (!a.A || !a.alpha1 || !a.alpha2 || !a.Wf || !a.cs1 || !a.cs2 || !a.amax_in || !a.out)
     return fail(JV_ERR_ARG, "hiftpair: needs A, both Snake alphas, fragment-order weights, both colscales, the measured bound and an output");
   if (a.out == a.A) return fail(JV_ERR_ARG, "hiftpair: the output must not alias the input (halo rows)");
-  if (a.ntaps < 1 || a.ntaps > 11 || !(a.ntaps & 1) || a.dil < 1 || (a.ntaps - 1) * a.dil > 56) return fail(JV_ERR_ARG, "hiftpair: odd kernel sizes up to 11, window up to 56 rows");
+  if ((a.ntaps != 3 && a.ntaps != 7 && a.ntaps != 11) || a.dil < 1 || (a.ntaps - 1) * a.dil > 56) return fail(JV_ERR_ARG, "hiftpair: kernel sizes 3, 7, 11, window up to 56 rows");
   if (!(a.l1max > 0.f) || !(a.e1 > 0.f) || !(a.e2 > 0.f)) return fail(JV_ERR_ARG, "hiftpair: needs the intermediate's bound (L1 norm, Snake extras)");
-  switch (C) {
-    case 64: return hp_launch<64, 2>(a, st);
-    case 128: return hp_launch<128, 2>(a, st);
-    default: return fail(JV_ERR_ARG, "hiftpair: 64 or 128 channels");
+  switch (C * 16 + a.ntaps) {      // (the kernel size is a template parameter: hiftpair_kernel.h)
+    case 64 * 16 + 3: return hp_launch<64, 2, 3>(a, st);
+    case 64 * 16 + 7: return hp_launch<64, 2, 7>(a, st);
+    case 64 * 16 + 11: return hp_launch<64, 2, 11>(a, st);
+    case 128 * 16 + 3: return hp_launch<128, 2, 3>(a, st);
+    case 128 * 16 + 7: return hp_launch<128, 2, 7>(a, st);
+    case 128 * 16 + 11: return hp_launch<128, 2, 11>(a, st);
+    default: return fail(JV_ERR_ARG, "hiftpair: 64 or 128 channels, kernel size 3, 7 or 11");
   }
 }
 

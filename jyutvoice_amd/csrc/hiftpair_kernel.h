@@ -66,7 +66,20 @@ template <int C, int NG> inline int hp_lds_bytes(int ntaps, int dil) {
   return ((w1 * 4 + 255) & ~255) + R * 16 + (C / 32) * 2 * wr * 64 + NG * (C / 32) * 16 * 36 * 4;
 }
 
-template <int C, int NG>
+template <int N, class F, int... Is>
+__device__ __forceinline__ void hp_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void hp_for(F&& f) {
+  hp_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+// KT: the kernel size, a template parameter -- the step sequence of both products is then straight-line code, every step's
+// weight buffer (step mod NB) and A-fragment parity (step mod 2) a compile-time constant.  (Chosen at run time through a
+// switch per step, the six (buffer, parity) combinations made the register allocator copy the buffers at every join: 567
+// spilled registers, and copies of registers with loads in flight are exactly what tools/check_rowgemm_isa.py forbids.)
+template <int C, int NG, int KT>
 __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftpair_kernel(const HiftPairArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char hc_lds[];
   constexpr int RT = HC_RT, RG = HC_RG;
@@ -80,7 +93,8 @@ __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftpair_kernel(const H
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kq = lane >> 4;
   const int grp = wave / CW, cp = wave % CW;    // row group, 32-column pair
-  const int k = p.ntaps, h2 = (k - 1) >> 1, h1 = (p.dil * (k - 1)) >> 1;
+  constexpr int k = KT;
+  const int h2 = (k - 1) >> 1, h1 = (p.dil * (k - 1)) >> 1;
   const int RO = R - (k - 1);                   // output rows of this workgroup
   const int m0 = blockIdx.x * RO;
   const int WR = R + (k - 1) * p.dil;           // window rows of x really used
@@ -89,8 +103,8 @@ __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftpair_kernel(const H
                                                       // reach discarded output rows only)
   const int PS = WRP * 64, CS = 2 * PS;         // plane and chunk strides of the window's image
   const int PS2 = WRP2 * 64, CS2 = 2 * PS2;     // ... and of the intermediate's, laid over it
-  const int KS1 = k * NCH;                      // 32-deep steps per convolution (even: NCH is)
-  const int KS = 2 * KS1;
+  constexpr int KS1 = k * NCH;                  // 32-deep steps per convolution (even: NCH is)
+  constexpr int KS = 2 * KS1;
   float* const wscale = reinterpret_cast<float*>(hc_lds);                                   // [WRP]: < 0 = the row reads as zero
   float* const yinv1 = reinterpret_cast<float*>(hc_lds + ((WRP * 4 + 255) & ~255));         // [R]: 1 / scale1 of the intermediate row's utterance
   float* const ysc2 = yinv1 + R;                                                            // [R]: scale2 of it; < 0 = the row reads as zero
@@ -106,9 +120,18 @@ __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftpair_kernel(const H
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) wp[nt][pl] = p.Wf + (long)pl * p.wf_plane + (long)(2 * cp + nt) * 512 + lane * 8;
   int wk = 0;
-  rg_u32x4 bq[2][2][2];
+  // NB weight buffers: a step's fragments are requested NB steps ahead.  Two (the trunk kernels' double buffer) is 1.5 steps
+  // of lookahead at the first wait -- at ONE wave per SIMD and workgroup, as here, less than an L2 round trip (rowblock's
+  // staggered schedule measured it: 930 cycles per step for a lone wave against 480 of MFMA issue); this kernel has the 16
+  // registers a third buffer costs.
+#ifndef JV_HP_WBUF
+#define JV_HP_WBUF 3
+#endif
+  constexpr int NB = JV_HP_WBUF;
+  static_assert(NB == 2 || NB == 3, "two or three weight buffers");
+  rg_u32x4 bq[NB][2][2];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) bq[i >> 2][(i >> 1) & 1][i & 1] = rg_u32x4{0u, 0u, 0u, 0u};
+  for (int i = 0; i < 4 * NB; ++i) bq[i >> 2][(i >> 1) & 1][i & 1] = rg_u32x4{0u, 0u, 0u, 0u};
   auto load_frag = [](rg_u32x4& dst, const unsigned short* ptr) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(ptr) : "memory");
   };
@@ -136,6 +159,11 @@ __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftpair_kernel(const H
   load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
   load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
   advance_w();
+  if constexpr (NB == 3) {
+    load_w(std::integral_constant<int, NB - 1>{}, std::integral_constant<int, 0>{});
+    load_w(std::integral_constant<int, NB - 1>{}, std::integral_constant<int, 1>{});
+    advance_w();
+  }
 
   // ---- per-row facts (one level of unconditional loads on clamped indices: rowconv_wd_kernel) ----
   auto slot_of = [&](const long row) -> int {
@@ -249,6 +277,7 @@ __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftpair_kernel(const H
   rg_wait_vmcnt<0>();
   landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
   landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
+  if constexpr (NB == 3) landed_w(bq[NB - 1][0][0], bq[NB - 1][0][1], bq[NB - 1][1][0], bq[NB - 1][1][1]);
   rg_lds_barrier();      // the window's image is complete
 
   // ---- the two products: step ks = (tap j = ks / NCH, chunk c = ks % NCH); A fragments of row tile mt at image row
@@ -266,8 +295,10 @@ __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftpair_kernel(const H
       for (int pl = 0; pl < 2; ++pl) af[par][mt][pl] = *reinterpret_cast<const rg_u32x4*>(a + pl * ips + mt * 1024);
   };
   int nc = 1, nj = 0;      // chunk and tap of the NEXT step
-  auto step = [&](auto par_tag, const bool last) {
-    constexpr int par = decltype(par_tag)::value;
+  // a step multiplies the A fragments of parity `par` (requested by the step before) with the weight buffer `buf` and
+  // refills that buffer for the step NB ahead
+  auto step = [&](auto buf_tag, auto par_tag, const bool last) {
+    constexpr int buf = decltype(buf_tag)::value, par = decltype(par_tag)::value;
     auto block = [&](auto nttag) {
       constexpr int nt = decltype(nttag)::value;
 #pragma unroll
@@ -276,40 +307,41 @@ __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftpair_kernel(const H
         auto mm = [&](const rg_u32x4& x, const rg_u32x4& y) {
           t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rg_f16x8, x), __builtin_bit_cast(rg_f16x8, y), t, 0, 0, 0);
         };
-        mm(af[par][mt][1], bq[par][nt][0]);      // smallest terms first, as everywhere
-        mm(af[par][mt][0], bq[par][nt][1]);
-        mm(af[par][mt][0], bq[par][nt][0]);
+        mm(af[par][mt][1], bq[buf][nt][0]);      // smallest terms first, as everywhere
+        mm(af[par][mt][0], bq[buf][nt][1]);
+        mm(af[par][mt][0], bq[buf][nt][0]);
         acc[mt][nt] = t;
       }
       __builtin_amdgcn_sched_barrier(0);
-      load_w(par_tag, nttag);
+      load_w(buf_tag, nttag);
       __builtin_amdgcn_sched_barrier(0);
     };
-    // this wave's memory operations in program order: ... W0(s+1), W1(s+1) | W0(s+2), <wait>, W1(s+2) | ...; needed at the wait:
-    // W0(s+1) and W1(s); behind W0(s+1): W1(s+1) and W0(s+2) = NWL loads (rowgemm_wa_kernel)
+    // this wave's memory operations in program order: ... W0(s+NB-1), W1(s+NB-1) | W0(s+NB), <wait>, W1(s+NB) | ...; needed at the
+    // wait: W0(s+1) and W1(s); behind W0(s+1): W1(s+1) .. W0(s+NB) = 2 (NB - 1) load pairs (rowgemm_wa_kernel's count at NB = 2)
     block(std::integral_constant<int, 0>{});
-    rg_wait_vmcnt<NWL>();
-    landed_w(bq[par][1][0], bq[par][1][1], bq[par ^ 1][0][0], bq[par ^ 1][0][1]);
+    rg_wait_vmcnt<NWL * (NB - 1)>();
+    landed_w(bq[buf][1][0], bq[buf][1][1], bq[(buf + 1) % NB][0][0], bq[(buf + 1) % NB][0][1]);
     if (!last) read_a(std::integral_constant<int, par ^ 1>{}, nc, nj);
     __builtin_amdgcn_sched_barrier(0);
     block(std::integral_constant<int, 1>{});
     advance_w();
     if (++nc == NCH) { nc = 0; ++nj; }
   };
-  auto product = [&]() {
+  // product P0 / KS1 (P0 = its first step's number over both products): weight buffer (P0 + i) % NB, A parity i & 1 (KS1 is even)
+  auto product = [&](auto p0_tag) {
+    constexpr int P0 = decltype(p0_tag)::value;
 #pragma unroll
     for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
     nc = 1; nj = 0;
     read_a(std::integral_constant<int, 0>{}, 0, 0);
-#pragma unroll 1
-    for (int ks = 0; ks < KS1; ks += 2) {
-      step(std::integral_constant<int, 0>{}, false);
-      step(std::integral_constant<int, 1>{}, ks + 2 >= KS1);
-    }
+    hp_for<KS1>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      step(std::integral_constant<int, (P0 + i) % NB>{}, std::integral_constant<int, i & 1>{}, i + 1 >= KS1);
+    });
   };
-  product();      // the intermediate, before its bias, x scale1 x 2^e
+  product(std::integral_constant<int, 0>{});      // the intermediate, before its bias, x scale1 x 2^e
 
   // ---- the intermediate: + bias -> mask -> Snake2 -> x scale2 -> planes, over the window's image ----
   rg_lds_barrier();      // every wave is done reading the window
@@ -363,7 +395,7 @@ __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftpair_kernel(const H
   }
   rg_lds_barrier();      // the intermediate's image is complete
   ips = PS2; ics = CS2; idil = 1;
-  product();
+  product(std::integral_constant<int, KS1>{});
 
   // ---- epilogue, per wave (hiftconv_kernel): 16 rows at a time through the wave's private patch; out = ((acc + b2) + x + res2)
   // * out_scale (+ previous out) for tile rows < RO ----
@@ -453,6 +485,7 @@ __global__ __launch_bounds__(64 * NG * (C / 32), 2) void hiftpair_kernel(const H
   rg_wait_vmcnt<0>();
   landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
   landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
+  if constexpr (NB == 3) landed_w(bq[NB - 1][0][0], bq[NB - 1][0][1], bq[NB - 1][1][0], bq[NB - 1][1][1]);
 }
 
 }  // namespace jv

@@ -63,6 +63,9 @@ struct ResnetW {
   // block1's three taps AND res_conv as a fourth fragment step per 32-channel chunk (k-step major fragments: steps 0 .. 3 NCH - 1
   // are block1's, 3 NCH .. 4 NCH - 1 res_conv's), plane stride 256 * 4 * Cin halves: rowconv_wd_kernel<RT, true> (registry.hip)
   const unsigned short* wf4 = nullptr;
+  // sqrt(255) max |ln1.g| + max |ln1.b|: the range of block1's LayerNorm, hence (with Mish(v) <= max(v, 0.31) and the time
+  // embedding's own maximum) of h2 -- the whole-resnet launch scales its LDS-resident h2 with it (rowres_kernel.h); 0 = n/a
+  float h2_bound = 0.f;
 };
 struct BtbW {
   LnW n1, n3;
@@ -144,6 +147,7 @@ struct Context {
   bool no_ffn_fuse = false;      // JV_NO_FFN_FUSE=1: ff.net.0 and ff.net.2 as two launches (the path rowffn_kernel is checked against)
   bool no_temb_pre = false;      // JV_NO_TEMB_PRE=1: the timestep embedding inside every Euler step instead of once per solve (flow.hip cfm_solve)
   bool no_ln_fold = false;       // JV_NO_LN_FOLD=1: a stage's first norm1 as its own launch (layernorm256_planes) instead of in the resnet's last convolution
+  bool no_res_pair = false;      // JV_NO_RES_PAIR=1: a resnet as two row-owning launches (block1 + res_conv, block2) instead of one (rowres_kernel.h)
   bool no_res_fold = false;      // JV_NO_RES_FOLD=1: a resnet's 1 x 1 res_conv as a tile-kernel launch of its own instead of inside block1's row-owning launch
   bool no_compact = false;       // JV_NO_COMPACT=1: ragged batches keep the uniform row geometry (every utterance padded to the longest; flow.hip cfm_solve)
   bool no_qkv_split = false;     // JV_NO_QKV_SPLIT=1: q|k|v stays inside the fused block launch at every batch size (flow.hip `qkv_split`)

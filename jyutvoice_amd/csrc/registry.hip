@@ -635,6 +635,11 @@ int finalize_model(Context& c, int model, hipStream_t st) {
       pk.wfrag(e.res[i].block1); pk.wfrag(e.res[i].block2);
       (void)pk.half3(e.res[i].res);
       pk.wfrag4(e.res[i]);
+      {
+        const float gm = pk.host_maxabs(e.res[i].ln1.g, EST_CH), bm = pk.host_maxabs(e.res[i].ln1.b, EST_CH);
+        const float hb = sqrtf(255.f) * gm + bm;
+        e.res[i].h2_bound = (hb == hb && hb > 0.f && hb < 1e30f) ? hb : 0.f;
+      }
       for (int j = 0; j < EST_NBLK; ++j) {
         const std::string b = stage[i] + "1." + S(j) + ".";
         BtbW& w = e.blk[i][j];

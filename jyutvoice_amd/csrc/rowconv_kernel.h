@@ -804,6 +804,7 @@ __global__ __launch_bounds__(512, 2) void rowconv_wd_kernel(const RowConvArgs p)
   landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
   landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
   asm volatile("" ::"v"(warm));
+  stamp();      // 7 (6 without the res_conv pass): every store of this wave acknowledged
 }
 
 

@@ -1,5 +1,6 @@
 // Host side of the row-owning fp16x3 GEMM (rowgemm_kernel.h): tile height choice and launch.
 #include "rowconv_kernel.h"
+#include "rowres_kernel.h"
 
 namespace jv {
 
@@ -198,6 +199,59 @@ int rowconv(const RowConvArgs& a, hipStream_t st) {
     case 4: return rc_launch<4>(a, st);
     case 5: return rc_launch<5>(a, st);
     default: return fail(JV_ERR_ARG, "rowconv: bad tile height");
+  }
+}
+
+namespace {
+template <int RT>
+int rr_launch(const RowResArgs& a, hipStream_t st) {
+  static bool raised[64] = {};
+  int dev = 0;
+  JV_HIP(hipGetDevice(&dev));
+  if (!raised[dev & 63]) {
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowres_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, rr_lds_bytes<RT>()));
+    raised[dev & 63] = true;
+  }
+  const bool prof = prof_on();
+  if (prof) prof_begin(st);
+  hipLaunchKernelGGL((rowres_kernel<RT>), dim3(cdiv(a.M, 16 * RT - 2)), dim3(512), rr_lds_bytes<RT>(), st, a);
+  if (prof) {
+    static const std::string name = std::string("rowres_h3<") + std::to_string(16 * RT) + "x256>";
+    const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M);
+    const double macs = 256.0 * (4.0 * a.Cin + 3.0 * 256);      // block1's three taps + res_conv, block2's three taps
+    const double bytes = 4.0 * (rows * (a.Cin + 256) + macs);   // x in, out rows, the weights (h2 and res never leave the chip)
+    prof_end(st, name.c_str(), 2.0 * rows * macs, bytes);
+  }
+  JV_HIP(hipGetLastError());
+  return JV_OK;
+}
+}  // namespace
+
+// does the whole-resnet launch keep the number of workgroup rounds of the two launches it replaces?  Its workgroups produce
+// 16 rt - 2 rows each (block2's causal halo), so a batch that just fills a round with 16 rt-row tiles may spill into the next
+bool rowres_fits(int M) {
+  const int rt = rowgemm_tile(M);
+  if (rt < 2) return false;
+  return cdiv(cdiv(M, 16 * rt - 2), 256) == cdiv(cdiv(M, 16 * rt), 256);
+}
+
+// a whole CausalResnetBlock1D in one launch (rowres_kernel.h)
+int rowres(const RowResArgs& a, hipStream_t st) {
+  if (a.M <= 0) return JV_OK;
+  if (!a.A || !a.Wf1 || !a.Wf2 || !a.cs1 || !a.cs2 || !a.csr || !a.amax_in || !a.out || !a.temb || !a.ln1_g || !a.ln1_b || !a.ln2_g || !a.ln2_b)
+    return fail(JV_ERR_ARG, "rowres: needs x, both fragment streams, the three column scales, the measured bound, both LayerNorms, the time embedding and an output");
+  if ((a.Cin & 63) || a.Cin < 64 || (a.lda & 3) || (a.ldo & 3) || !(a.h2_bound > 0.f)) return fail(JV_ERR_ARG, "rowres: Cin % 64 == 0, aligned strides and the h2 bound required");
+  if (a.slot_S < 0 && !a.row_slot) return fail(JV_ERR_ARG, "rowres: the compact geometry needs the row -> utterance table");
+  if (a.lnf_out && (!a.lnf_g || !a.lnf_b || !(a.lnf_scale > 0.f) || a.lnf_plane <= 0 || a.ldo != 256))
+    return fail(JV_ERR_ARG, "rowres: the following LayerNorm needs gain, offset, a scale, a plane stride and 256-wide output rows");
+  const int rt = rowgemm_tile(a.M);
+  // the kernel reads whole window rows up to the last tile's end: they must exist in the input buffer or read as masked (a_rows clamps)
+  switch (rt) {
+    case 2: return rr_launch<2>(a, st);
+    case 3: return rr_launch<3>(a, st);
+    case 4: return rr_launch<4>(a, st);
+    case 5: return rr_launch<5>(a, st);
+    default: return fail(JV_ERR_ARG, "rowres: no row-owning tile height for this row count");
   }
 }
 

@@ -513,6 +513,45 @@ def test_res_fold_matches_separate_launch(monkeypatch):
         assert not torch.equal(f, s)      # (the two routes are different code: identical bits would mean the switch does nothing)
 
 
+def test_res_pair_matches_two_launches(monkeypatch):
+    """A whole CausalResnetBlock1D in ONE launch (rowres_kernel.h: block1 + res_conv, the time embedding, block2; h2 stays in LDS
+    and takes its fp16x3 scale from a bound -- LayerNorm's range from the weights + the embedding's maximum -- instead of a measured
+    maximum) against the two row-owning launches it replaces (JV_NO_RES_PAIR=1).  The three fp16 planes hold an fp32 value
+    exactly under any power-of-two scale and both routes add the products in the same order, so the mels are EQUAL (the
+    2e-5 cross-regime bound is the fallback written here for a low plane that underflows under the smaller scale) -- tile
+    heights 5 (32 utterances), 2 (ragged 8), 4 (ragged 20: a last workgroup partly past the end), compact and uniform
+    geometry.  The built-in profiler proves the switch changes the launches: 13 of the 14 resnets x 2 steps fused"""
+    import jyutvoice_amd
+    from jyutvoice_amd import synth, engine
+    sd = synth.tts_state_dict(fixed_duration=1.5)
+    keys = ("x", "x_lengths", "lang", "tone", "word_pos", "syllable_pos", "spk_embed")
+    cases = [synth.batch(32, 150), synth.batch(8, 150, first_index=40, lengths=[150 - 11 * i for i in range(8)]),
+             synth.batch(20, 131, first_index=7, lengths=[131 - 3 * i for i in range(20)])]
+
+    def run():
+        tts, _ = jyutvoice_amd.build_default("cuda:0")
+        tts.load_state_dict(sd)
+        mels = [tts.synthesise(*[b[k] for k in keys], None, n_timesteps=2, batched=True)["mel"].cpu() for b in cases]
+        engine.profile_enable(True)
+        try:
+            tts.synthesise(*[cases[0][k] for k in keys], None, n_timesteps=2, batched=True)
+            rep = engine.profile_report()
+        finally:
+            engine.profile_enable(False)
+        return mels, rep
+
+    fused, rep_f = run()
+    monkeypatch.setenv("JV_NO_RES_PAIR", "1")
+    separate, rep_s = run()
+    n_f = sum(v["launches"] for k, v in rep_f.items() if k.startswith("rowres_h3"))
+    n_s = sum(v["launches"] for k, v in rep_s.items() if k.startswith("rowres_h3"))
+    assert n_f == 2 * 13 and n_s == 0, (n_f, n_s)      # (the first resnet's input has no measured bound: never fused)
+    for f, s in zip(fused, separate):
+        assert torch.isfinite(f).all()
+        assert float((f - s).abs().max()) <= 2e-5
+    assert torch.equal(fused[0], separate[0])
+
+
 def test_timestep_embeddings_once_per_solve(monkeypatch):
     """cfm_solve computes the timestep embedding of every Euler step ahead of the loop (three GEMMs of n_timesteps rows) and
     each step copies its row into place; JV_NO_TEMB_PRE=1 computes it inside every step for all 2B (identical) rows, as the

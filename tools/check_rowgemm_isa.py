@@ -147,7 +147,7 @@ def main():
                 print(r.stderr[-3000:])
                 return 2
     n_k = n_bad = 0
-    for m in re.finditer(r"^(_ZN2jv\d+(rowgemm_wd_kernel|rowgemm_wa_kernel|rowffn_kernel|rowconv_wd_kernel|rowblock_kernel|hiftconv_kernel|hiftpair_kernel)\w+):\s*;.*?\n(.*?)\.end_amdhsa_kernel", s, re.S | re.M):
+    for m in re.finditer(r"^(_ZN2jv\d+(rowgemm_wd_kernel|rowgemm_wa_kernel|rowffn_kernel|rowconv_wd_kernel|rowblock_kernel|rowres_kernel|hiftconv_kernel|hiftpair_kernel)\w+):\s*;.*?\n(.*?)\.end_amdhsa_kernel", s, re.S | re.M):
         name, body = m.group(1), m.group(3)
         body = body.split("s_endpgm")[0]
         n_loads, bad = check_kernel(name, body)

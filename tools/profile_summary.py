@@ -20,6 +20,9 @@ def short(name):
     m = re.search(r"rowblock_kernel<(\d+), (true|false|0|1)(?:, (?:true|false|0|1))?>", name)      # (<RT, QKV, STAG>)
     if m:
         return f"rowblock_h3<{16 * int(m.group(1))}x256{',qkv' if m.group(2) in ('true', '1') else ''}>"
+    m = re.search(r"rowres_kernel<(\d+)>", name)      # a whole resnet in one launch
+    if m:
+        return f"rowres_h3<{16 * int(m.group(1))}x256>"
     m = re.search(r"rowffn_kernel<(\d+)>", name)
     if m:
         return f"rowffn_h3<{16 * int(m.group(1))}x256>"
@@ -29,7 +32,7 @@ def short(name):
     m = re.search(r"attn64_s_kernel<(\d), \d+(?:, \d+)?>", name)
     if m:
         return f"attn64_s<{64 * int(m.group(1))} q>"
-    m = re.search(r"hiftpair_kernel<(\d+), (\d+)>", name)
+    m = re.search(r"hiftpair_kernel<(\d+), (\d+)(?:, \d+)?>", name)
     if m:
         return f"hiftpair_h3<{80 * int(m.group(2))}x{m.group(1)},snake>"
     m = re.search(r"hiftconv_kernel<(\d+), (\d+)>", name)
