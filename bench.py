@@ -371,6 +371,31 @@ def main():
                     "sum": round(sum(med), 3),
                     "measured": "events on the launch stream at the stage boundaries, 3 passes outside the timed region, median"}
 
+    # The default build runs 13 of the 14 stages' first q | k | v INSIDE the preceding resnet's launch (rowres_kernel<RT, true>), so
+    # the profiler's conv-stack group -- per launch -- then holds those products too.  The stack by itself (resnets, down / up /
+    # final convolutions, final projection: what the north star's HBM fraction and VERDICT r3's 13 ms are about) is measured
+    # here, after everything timed: the same weights re-loaded with JV_NO_RES_QKV=1 (the C ABI builds a new context and reads
+    # the switch), one warm pass, one pass under the profiler, then the default context restored.
+    cs_alone = None
+    if profile and rank == 0 and not os.environ.get("JV_NO_RES_QKV") and not os.environ.get("JV_NO_RES_PAIR"):
+        os.environ["JV_NO_RES_QKV"] = "1"
+        try:
+            tts.load_state_dict(synth.tts_state_dict(fixed_duration=1.5))
+            if args.workload == "c2":
+                eng = get_runtime(device).ensure(B, T, Tt)
+            step(gather=False)
+            torch.cuda.synchronize(device)
+            engine.profile_enable(True)
+            step(gather=False)
+            torch.cuda.synchronize(device)
+            engine.profile_enable(False)
+            cs_alone = engine.profile_report().get("_group:flow_conv_stack")
+        finally:
+            os.environ.pop("JV_NO_RES_QKV", None)
+            tts.load_state_dict(synth.tts_state_dict(fixed_duration=1.5))
+            if args.workload == "c2":
+                eng = get_runtime(device).ensure(B, T, Tt)
+
     if rank == 0:
         frames = (args.total_batch if args.strong else world * B) * T * args.steps
         if args.ragged:      # every rank draws its own lengths from the same distribution; rank 0's sum stands for each
@@ -420,6 +445,17 @@ def main():
                                  "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                  "launches_per_pass": cs["launches"] // prof_steps,
                                  "alg_tflops": round(cs["flops"] / (cs["ms"] * 1e-3) / 1e12, 2)}
+            if cs_alone and cs_alone["ms"] > 0:
+                # (the numbers above are the group as the default build launches it: q | k | v of 13 stages inside; these are the stack alone)
+                one = n_steps * (96064.0 * 2 * (valid_frames if args.ragged else B * T) + 29.5e6)
+                g1 = one / (cs_alone["ms"] * 1e-3) / 1e9
+                out["conv_stack"]["includes"] = ("the first q | k | v of 13 of the 14 stages, computed inside the resnet launch that precedes it "
+                                                 "(rowres_kernel<RT, true>): its time and FLOP are in ms_per_pass / alg_tflops, not in alg_bytes_per_pass")
+                out["conv_stack"]["stack_alone"] = {
+                    "ms_per_pass": round(cs_alone["ms"], 3), "achieved": round(g1, 1), "unit": "GB/s", "frac": round(g1 / HBM_PEAK_GBS, 4),
+                    "launches_per_pass": cs_alone["launches"], "alg_tflops": round(cs_alone["flops"] / (cs_alone["ms"] * 1e-3) / 1e12, 2),
+                    "how": "one pass under the profiler after the timed region, the same weights re-loaded with JV_NO_RES_QKV=1 "
+                           "(q | k | v as launches of their own, outside the group): the Conv1d stack as VERDICT r3 measured it"}
         if kern:
             tot_ms = sum(v["ms"] for v in kern.values())
             name, d = max(((k, v) for k, v in kern.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])

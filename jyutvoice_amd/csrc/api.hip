@@ -135,6 +135,7 @@ int jv_create(jv_context** out, int device, int max_batch, int max_frames, int m
   c.no_compact = getenv("JV_NO_COMPACT") != nullptr;
   c.no_res_fold = getenv("JV_NO_RES_FOLD") != nullptr;
   c.no_res_pair = getenv("JV_NO_RES_PAIR") != nullptr;
+  c.no_res_qkv = getenv("JV_NO_RES_QKV") != nullptr;
   c.no_ln_fold = getenv("JV_NO_LN_FOLD") != nullptr;
   c.no_temb_pre = getenv("JV_NO_TEMB_PRE") != nullptr;
   c.no_attn_planes = getenv("JV_NO_ATTN_PLANES") != nullptr;

@@ -348,7 +348,10 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
            r.h2_bound > 0.f && r.block1.colscale && r.block2.colscale && r.res.colscale && r.block1.Cin == ldin && !(ldin & 63) &&
            rowres_fits((int)g.M);
   };
-  auto resnet = [&](int i, const float* in, int ldin, float* out, int ldo, const BtbW* follow = nullptr, bool* followed = nullptr) -> int {
+  // `qkv_done` (non-null: the caller's stage can take it): the launch also produced the following block's q | k | v
+  auto resnet = [&](int i, const float* in, int ldin, float* out, int ldo, const BtbW* follow = nullptr, bool* followed = nullptr,
+                    bool* qkv_done = nullptr) -> int {
+    if (qkv_done) *qkv_done = false;
     ConvStackScope scope;
     const ResnetW& r = e.res[i];
     // The whole resnet in ONE launch (rowres_kernel.h) where every piece has its row-owning form: a trunk input with a
@@ -375,6 +378,13 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
         a.lnf_out = reinterpret_cast<unsigned short*>(w.ln); a.lnf_plane = (long)w.rows_alloc * 256;
         a.lnf_g = follow->n1.g; a.lnf_b = follow->n1.b; a.lnf_scale = follow->qkv.a_scale;
         *followed = true;
+        if (qkv_done) {      // ... and its to_q | to_k | to_v over those planes, which then never leave LDS (btb_rg's buffers and scales)
+          a.lnf_out = nullptr;
+          a.Wqf = follow->qkv.wf; a.wqf_plane = (long)follow->qkv.N * follow->qkv.Cin; a.csq = follow->qkv.colscale;
+          a.q = w.qkv; a.kv2 = reinterpret_cast<unsigned short*>(w.qkv + (long)w.rows_alloc * 512); a.kv2_plane = (long)w.rows_alloc * 1024;
+          a.k_scale = follow->k_scale; a.v_scale = follow->v_scale;
+          *qkv_done = true;
+        }
       }
       return rowres(a, st);
     }
@@ -628,10 +638,11 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
     return all;
   };
   // `ln_first`: the first block's norm1 planes are already in w.ln (written by the resnet's last convolution)
-  auto stage_blocks = [&](const BtbW* blk, float* h, float* last_out, int last_ldo, bool ln_first = false) -> int {
+  // `qkv_first`: ... and its q | k | v too (the whole-resnet launch's product 3)
+  auto stage_blocks = [&](const BtbW* blk, float* h, float* last_out, int last_ldo, bool ln_first = false, bool qkv_first = false) -> int {
     const bool all = stage_all_rg(blk);
     if (g.uoff && (!all || c.no_attn_planes)) return fail(JV_ERR_STATE, "flow: the compact geometry exists on the row-owning kernels only");
-    bool qkv_ready = false;
+    bool qkv_ready = qkv_first && all && !c.no_attn_planes;
     for (int j = 0; j < EST_NBLK; ++j) {
       const bool last = j == EST_NBLK - 1;
       if (all) JV_TRY(btb_rg(blk[j], last ? nullptr : &blk[j + 1], j > 0 || ln_first, qkv_ready, &qkv_ready, h, last ? last_out : h, last ? last_ldo : 256));
@@ -642,10 +653,15 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
 
   // down: resnet -> 4 blocks (result doubles as the skip) -> causal conv
   // (a stage on the row-owning kernels takes its first norm1 from the resnet's last convolution)
-  bool lnf = false;
+  bool lnf = false, qkv0 = false;
+  // may the resnet ahead of a stage run the stage's first q | k | v?  The full-chip regime of the row-owning blocks (no column split)
+  auto qkv_of = [&](const BtbW* blk) -> bool* {
+    const GemmW& m = blk[0].qkv;
+    return (!c.no_res_qkv && !c.no_attn_planes && stage_all_rg(blk) && qkv_split <= 1 && m.wf && m.N == 1536 && m.Cin == 256 && !m.bias) ? &qkv0 : nullptr;
+  };
   auto follow_of = [&](const BtbW* blk) -> const BtbW* { return (stage_all_rg(blk) || sk_blocks) ? blk : nullptr; };
-  JV_TRY(resnet(0, w.xin, 320, w.h, 256, follow_of(e.blk[0]), &lnf));
-  JV_TRY(stage_blocks(e.blk[0], w.h, skip, 512, lnf));
+  JV_TRY(resnet(0, w.xin, 320, w.h, 256, follow_of(e.blk[0]), &lnf, qkv_of(e.blk[0])));
+  JV_TRY(stage_blocks(e.blk[0], w.h, skip, 512, lnf, qkv0));
   {
     ConvStackScope scope;
     ConvGemmArgs a = base_args(g, skip, 512, e.down_conv, w.h, 256);
@@ -661,14 +677,14 @@ int estimator_body(Context& c, const Geo& g, hipStream_t st) {
   const bool mid_pair = (EST_NMID % 2 == 0);
   for (int i = 1; i <= EST_NMID; ++i) {
     float* const dst = (mid_pair && res_pair_ok(i, trunk, 256)) ? (trunk == w.h ? w.h2 : w.h) : trunk;
-    JV_TRY(resnet(i, trunk, 256, dst, 256, follow_of(e.blk[i]), &lnf));
+    JV_TRY(resnet(i, trunk, 256, dst, 256, follow_of(e.blk[i]), &lnf, qkv_of(e.blk[i])));
     trunk = dst;
-    JV_TRY(stage_blocks(e.blk[i], trunk, i == EST_NMID ? w.cat : trunk, i == EST_NMID ? 512 : 256, lnf));
+    JV_TRY(stage_blocks(e.blk[i], trunk, i == EST_NMID ? w.cat : trunk, i == EST_NMID ? 512 : 256, lnf, qkv0));
   }
   if (trunk != w.h) return fail(JV_ERR_STATE, "flow: the mid stages left the trunk in the scratch buffer");
   // up: resnet(cat[x, skip]) -> 4 blocks -> causal conv -> final block -> 1x1 projection
-  JV_TRY(resnet(EST_NRES - 1, w.cat, 512, w.h, 256, follow_of(e.blk[EST_NRES - 1]), &lnf));
-  JV_TRY(stage_blocks(e.blk[EST_NRES - 1], w.h, w.h, 256, lnf));
+  JV_TRY(resnet(EST_NRES - 1, w.cat, 512, w.h, 256, follow_of(e.blk[EST_NRES - 1]), &lnf, qkv_of(e.blk[EST_NRES - 1])));
+  JV_TRY(stage_blocks(e.blk[EST_NRES - 1], w.h, w.h, 256, lnf, qkv0));
   {
     ConvStackScope scope;
     ConvGemmArgs a = base_args(g, w.h, 256, e.up_conv, w.h2, 256);

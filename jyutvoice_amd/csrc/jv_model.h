@@ -147,6 +147,7 @@ struct Context {
   bool no_ffn_fuse = false;      // JV_NO_FFN_FUSE=1: ff.net.0 and ff.net.2 as two launches (the path rowffn_kernel is checked against)
   bool no_temb_pre = false;      // JV_NO_TEMB_PRE=1: the timestep embedding inside every Euler step instead of once per solve (flow.hip cfm_solve)
   bool no_ln_fold = false;       // JV_NO_LN_FOLD=1: a stage's first norm1 as its own launch (layernorm256_planes) instead of in the resnet's last convolution
+  bool no_res_qkv = false;       // JV_NO_RES_QKV=1: a stage's first q | k | v as its own launch (rowgemm_wa) instead of inside the resnet's (rowres_kernel.h)
   bool no_res_pair = false;      // JV_NO_RES_PAIR=1: a resnet as two row-owning launches (block1 + res_conv, block2) instead of one (rowres_kernel.h)
   bool no_res_fold = false;      // JV_NO_RES_FOLD=1: a resnet's 1 x 1 res_conv as a tile-kernel launch of its own instead of inside block1's row-owning launch
   bool no_compact = false;       // JV_NO_COMPACT=1: ragged batches keep the uniform row geometry (every utterance padded to the longest; flow.hip cfm_solve)

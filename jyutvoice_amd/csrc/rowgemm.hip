@@ -203,23 +203,25 @@ int rowconv(const RowConvArgs& a, hipStream_t st) {
 }
 
 namespace {
-template <int RT>
+template <int RT, bool QKV>
 int rr_launch(const RowResArgs& a, hipStream_t st) {
   static bool raised[64] = {};
   int dev = 0;
   JV_HIP(hipGetDevice(&dev));
   if (!raised[dev & 63]) {
-    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowres_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, rr_lds_bytes<RT>()));
+    JV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowres_kernel<RT, QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, rr_lds_bytes<RT>()));
     raised[dev & 63] = true;
   }
   const bool prof = prof_on();
   if (prof) prof_begin(st);
-  hipLaunchKernelGGL((rowres_kernel<RT>), dim3(cdiv(a.M, 16 * RT - 2)), dim3(512), rr_lds_bytes<RT>(), st, a);
+  hipLaunchKernelGGL((rowres_kernel<RT, QKV>), dim3(cdiv(a.M, 16 * RT - 2)), dim3(512), rr_lds_bytes<RT>(), st, a);
   if (prof) {
-    static const std::string name = std::string("rowres_h3<") + std::to_string(16 * RT) + "x256>";
+    static const std::string name = std::string("rowres_h3<") + std::to_string(16 * RT) + "x256" + (QKV ? ",qkv>" : ">");
     const double rows = (double)(a.alg_rows > 0 ? a.alg_rows : a.M);
-    const double macs = 256.0 * (4.0 * a.Cin + 3.0 * 256);      // block1's three taps + res_conv, block2's three taps
-    const double bytes = 4.0 * (rows * (a.Cin + 256) + macs);   // x in, out rows, the weights (h2 and res never leave the chip)
+    // block1's three taps + res_conv, block2's three taps (+ the following block's to_q | to_k | to_v)
+    const double macs = 256.0 * (4.0 * a.Cin + 3.0 * 256) + (QKV ? 256.0 * 1536 : 0.0);
+    // x in, out rows, the weights (h2 and res never leave the chip) (+ q rows and the k / v planes out)
+    const double bytes = 4.0 * (rows * (a.Cin + 256 + (QKV ? 1536 : 0)) + macs);
     prof_end(st, name.c_str(), 2.0 * rows * macs, bytes);
   }
   JV_HIP(hipGetLastError());
@@ -244,13 +246,17 @@ int rowres(const RowResArgs& a, hipStream_t st) {
   if (a.slot_S < 0 && !a.row_slot) return fail(JV_ERR_ARG, "rowres: the compact geometry needs the row -> utterance table");
   if (a.lnf_out && (!a.lnf_g || !a.lnf_b || !(a.lnf_scale > 0.f) || a.lnf_plane <= 0 || a.ldo != 256))
     return fail(JV_ERR_ARG, "rowres: the following LayerNorm needs gain, offset, a scale, a plane stride and 256-wide output rows");
+  const bool qkv = a.Wqf != nullptr;
+  if (qkv && (!a.csq || !a.q || !a.kv2 || a.kv2_plane <= 0 || !(a.k_scale > 0.f) || !(a.v_scale > 0.f) || !a.lnf_g || !a.lnf_b || !(a.lnf_scale > 0.f) ||
+              a.wqf_plane <= 0 || a.ldo != 256))
+    return fail(JV_ERR_ARG, "rowres: q | k | v needs its fragments, column scales, outputs, the attention scales and the following LayerNorm");
   const int rt = rowgemm_tile(a.M);
   // the kernel reads whole window rows up to the last tile's end: they must exist in the input buffer or read as masked (a_rows clamps)
   switch (rt) {
-    case 2: return rr_launch<2>(a, st);
-    case 3: return rr_launch<3>(a, st);
-    case 4: return rr_launch<4>(a, st);
-    case 5: return rr_launch<5>(a, st);
+    case 2: return qkv ? rr_launch<2, true>(a, st) : rr_launch<2, false>(a, st);
+    case 3: return qkv ? rr_launch<3, true>(a, st) : rr_launch<3, false>(a, st);
+    case 4: return qkv ? rr_launch<4, true>(a, st) : rr_launch<4, false>(a, st);
+    case 5: return qkv ? rr_launch<5, true>(a, st) : rr_launch<5, false>(a, st);
     default: return fail(JV_ERR_ARG, "rowres: no row-owning tile height for this row count");
   }
 }

@@ -15,7 +15,12 @@
 //      slab -> res_conv's rows of this wave's OUTPUT rows, kept in registers;
 //   3. product 2 -- block2's 24 steps over the resident image (row offsets 0, 1, 2), A fragments prefetched a step ahead;
 //   4. epilogue 2 -- rowconv_wd_kernel's: + bias, LayerNorm, Mish, mask, + res -> out rows (+ the following block's
-//      LayerNorm1 planes, + measured-bound tracking).
+//      LayerNorm1 planes, + measured-bound tracking);
+//   5. (QKV) product 3 -- the following block's to_q | to_k | to_v over those LayerNorm1 planes, which then stay in LDS (the
+//      image of product 2 is free): rowblock_kernel's phase C, six 256-column chunks of 8 steps, per-wave chunk epilogues
+//      through patches over the slab, q as fp32 rows, k and v as scaled fp16 planes -- the stage's first attention follows
+//      the resnet directly (as a launch of its own, rowgemm_wa_kernel, the same product took 48.7 us where phase C's
+//      stamps show 31).  Same K order and epilogue expressions as rowgemm_wa_kernel: the same bits.
 // block2's causal window needs h2 rows m - 2 .. m: the workgroup computes R rows of h2 (global rows m0 - 2 .. m0 + R - 3) and
 // RO = R - 2 output rows (m0 .. m0 + R - 3); 2.5 % of product 1 is recomputed by the neighbour (250 workgroups instead of 244
 // at the benchmarked size: still one round of the chip).
@@ -63,12 +68,20 @@ struct RowResArgs {
   long lnf_plane;
   const float *lnf_g, *lnf_b;
   float lnf_scale;
+  // (rowres_kernel<RT, true>) the following block's q | k | v from those planes (RowBlockArgs' phase C: N = 1536, K = 256, no bias)
+  const unsigned short* Wqf;         // fragment order, plane stride wqf_plane halves
+  long wqf_plane;
+  const float* csq;
+  float* q;                          // fp32 rows [., 512]
+  unsigned short* kv2;               // planes [2][rows][1024]: k * k_scale in columns 0..511, v * v_scale in 512..1023
+  long kv2_plane;
+  float k_scale, v_scale;
   long alg_rows;
 };
 
 template <int RT> constexpr int rr_lds_bytes() { return 16 * rgw_stage_bytes<RT>(); }
 
-template <int RT>
+template <int RT, bool QKV>
 __global__ __launch_bounds__(512, 2) void rowres_kernel(const RowResArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rr_lds[];
   constexpr int R = 16 * RT, RO = R - 2, WR = R + 2;
@@ -322,6 +335,10 @@ __global__ __launch_bounds__(512, 2) void rowres_kernel(const RowResArgs p) {
   landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
   landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
   asm volatile("" ::"v"(warm), "v"(warm2));
+  // (QKV) to_q | to_k | to_v's fragments into this XCD's L2 a whole product ahead: cold, every step of product 3 began with
+  // an HBM round trip taken by all workgroups at once -- 47 us for the product, what it takes as a launch of its own
+  float warm3 = 0.f;
+  if constexpr (QKV) warm3 = warm_lines(p.Wqf, p.wqf_plane, ((long)1536 * 256 * 2) >> 7);
   set_wbase(p.Wf2, p.wf2_plane);
   woff = 0; wj = 0; wc = 0; wnj = 3; wnch = 8;
   load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -392,6 +409,7 @@ __global__ __launch_bounds__(512, 2) void rowres_kernel(const RowResArgs p) {
     res[j] = *reinterpret_cast<const rg_f32x4*>(slab + rb_slab(srow, 4 * lane)) * (csr * bcast_f(f_invo, j)) + br;
   }
   rg_wait_vmcnt<0>();      // block2's first fragments
+  asm volatile("" ::"v"(warm3));      // (issued an epilogue ago)
   landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
   landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
   rg_lds_barrier();      // the image is complete (and the slab has been read: epilogue 2 writes it again)
@@ -458,12 +476,18 @@ __global__ __launch_bounds__(512, 2) void rowres_kernel(const RowResArgs p) {
   const rg_f32x4 g2 = *reinterpret_cast<const rg_f32x4*>(p.ln2_g + 4 * lane);
   const rg_f32x4 o2 = *reinterpret_cast<const rg_f32x4*>(p.ln2_b + 4 * lane);
   rg_f32x4 gf = {1.f, 1.f, 1.f, 1.f}, of = {0.f, 0.f, 0.f, 0.f};
-  if (p.lnf_out) {
+  if (QKV || p.lnf_out) {
     gf = *reinterpret_cast<const rg_f32x4*>(p.lnf_g + 4 * lane);
     of = *reinterpret_cast<const rg_f32x4*>(p.lnf_b + 4 * lane);
   }
+  // (QKV) product 3's walker: chunk qc (256 of the 1536 columns), step qks -> fragment step qks, column blocks 16 qc ..
+  int qks = 0, qc = 0;
+  auto advance_q = [&]() {      // past the end: wrap around to weights that exist
+    if (++qks == 8) { qks = 0; if (++qc == 6) qc = 0; }
+    woff = ((long)qks * 96 + qc * 16) * 512;
+  };
   acc_to_slab(acc);      // (the slab was last read before product 2's barrier)
-  rg_lds_barrier();
+  rg_lds_barrier();      // (and every wave is done reading the image: the LayerNorm1 planes go over it below)
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
     rg_f32x4 v[RT];
@@ -504,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void rowres_kernel(const RowResArgs p) {
       v[j] = v[j] + res[jj];
       if (ok[j]) *(__attribute__((address_space(1))) rg_f32x4*)(p.out + (long)(drow0 + j) * p.ldo + 4 * lane) = v[j];
     }
-    if (p.lnf_out) {      // (uniform) the following block's norm1 of the stored rows -> operand planes (rowconv_wd_kernel)
+    if (QKV || p.lnf_out) {      // (uniform) the following block's norm1 of the stored rows -> operand planes (rowconv_wd_kernel)
       float sum[RT], sq[RT];
 #pragma unroll
       for (int j = 0; j < RT; ++j) sum[j] = wave_sum((v[j][0] + v[j][1]) + (v[j][2] + v[j][3]));
@@ -523,7 +547,12 @@ __global__ __launch_bounds__(512, 2) void rowres_kernel(const RowResArgs p) {
         const rg_f32x4 y = (v[j] - mean) * bcast_f(rstd_l, j) * gf + of;
         const Split2 s0 = split2h_pair(y[0] * p.lnf_scale, y[1] * p.lnf_scale);
         const Split2 s1 = split2h_pair(y[2] * p.lnf_scale, y[3] * p.lnf_scale);
-        if (ok[j]) {
+        if constexpr (QKV) {      // the operand image of product 3 (rows >= RO / past the end: never stored, and a row's product reads its own row only)
+          const int trow = wave * NRW + ps * RT + j;
+          unsigned char* d = rr_lds + (lane >> 3) * STAGE + trow * 64 + (((((lane & 7) >> 1) ^ rg_key(trow))) << 4) + (lane & 1) * 8;
+          *reinterpret_cast<rg_u32x2*>(d) = rg_u32x2{s0.h, s1.h};
+          *reinterpret_cast<rg_u32x2*>(d + XP) = rg_u32x2{s0.l, s1.l};
+        } else if (ok[j]) {
           unsigned short* const o2p = p.lnf_out + (long)(drow0 + j) * 256 + 4 * lane;
           *(__attribute__((address_space(1))) rg_u32x2*)(o2p) = rg_u32x2{s0.h, s1.h};
           *(__attribute__((address_space(1))) rg_u32x2*)(o2p + p.lnf_plane) = rg_u32x2{s0.l, s1.l};
@@ -543,6 +572,136 @@ __global__ __launch_bounds__(512, 2) void rowres_kernel(const RowResArgs p) {
 #pragma unroll
           for (int o = 32; o > 0; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o));
           if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(p.amax_out + __builtin_amdgcn_readlane(f_slot, jj)), u);
+        }
+      }
+    }
+  }
+
+  // ================================ product 3 (QKV): rowblock_kernel's phase C over the LayerNorm1 image ================================
+  if constexpr (QKV) {
+    // product 2's wrapped-around loads land in registers nothing reads; then q | k | v's first two steps are requested (HERE, behind
+    // the row pass: requested ahead of it the 32 fragment registers pushed the pass's values into scratch)
+    rg_wait_vmcnt<0>();
+    landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
+    landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
+    set_wbase(p.Wqf, p.wqf_plane);
+    woff = 0;
+    load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    advance_q();
+    load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    advance_q();
+    rg_lds_barrier();      // the image is complete; the slab has been read: the patches go over it
+    rg_wait_vmcnt<0>();      // (the fragments' round trip passes under the barrier; the row stores are waited for with them)
+    landed_w(bq[0][0][0], bq[0][0][1], bq[0][1][0], bq[0][1][1]);
+    landed_w(bq[1][0][0], bq[1][0][1], bq[1][1][0], bq[1][1][1]);
+    constexpr long LDQ = 512, LDKV = 1024;
+    constexpr int NPATCH = RT >= 3 ? 2 : 1;      // (RT = 2: the slab is 32 KB, eight pairs of patches are 36)
+    const float inv_q = 1.0f / p.lnf_scale;
+    float* const ws0 = slab + wave * (NPATCH * 16 * 36);
+    const int prow = lane >> 3, pc4 = (lane & 7) * 4;
+    rg_u32x4 af[2][RT][2];
+    const int a_off = r16 * 64 + ((kq ^ rg_key(r16)) << 4);
+    auto read_a = [&](auto par_tag, const int ks) {
+      constexpr int par = decltype(par_tag)::value;
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) af[par][mt][pl] = *reinterpret_cast<const rg_u32x4*>(rr_lds + ks * STAGE + a_off + pl * XP + mt * 1024);
+    };
+    bool waited = true;      // (the wait was done ahead of an epilogue's memory operations: rowblock_kernel's step)
+    auto step = [&](auto par_tag, const int ks_next) {
+      constexpr int par = decltype(par_tag)::value;
+      auto block = [&](auto nttag) {
+        constexpr int nt = decltype(nttag)::value;
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt) {
+          rg_f32x4 t = acc[mt][nt];
+          auto mm = [&](const rg_u32x4& x, const rg_u32x4& y) {
+            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rg_f16x8, x), __builtin_bit_cast(rg_f16x8, y), t, 0, 0, 0);
+          };
+          mm(af[par][mt][1], bq[par][nt][0]);
+          mm(af[par][mt][0], bq[par][nt][1]);
+          mm(af[par][mt][0], bq[par][nt][0]);
+          acc[mt][nt] = t;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(par_tag, nttag);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      block(std::integral_constant<int, 0>{});
+      if (!waited) rg_wait_vmcnt<NWL>();
+      waited = false;
+      landed_w(bq[par][1][0], bq[par][1][1], bq[par ^ 1][0][0], bq[par ^ 1][0][1]);
+      if (ks_next >= 0) read_a(std::integral_constant<int, par ^ 1>{}, ks_next);
+      __builtin_amdgcn_sched_barrier(0);
+      block(std::integral_constant<int, 1>{});
+      advance_q();
+    };
+    read_a(std::integral_constant<int, 0>{}, 0);
+#pragma unroll 1
+    for (int c = 0; c < 6; ++c) {
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int ks = 0; ks < 8; ks += 2) {
+        step(std::integral_constant<int, 0>{}, ks + 1);
+        // (the last step of a chunk requests stage 0 again: the next chunk's first step)
+        step(std::integral_constant<int, 1>{}, ks + 2 < 8 ? ks + 2 : (c + 1 < 6 ? 0 : -1));
+      }
+      if (c + 1 < 6) {
+        rg_wait_vmcnt<2>();
+        waited = true;
+      }
+      // the chunk's epilogue, per wave, through its private 16 x 36-float patches: q -> fp32 rows, k / v -> planes
+      const int nw = c * 256 + wave * 32 + pc4;
+      const float sc = c < 4 ? p.k_scale : p.v_scale;
+      if (c < 2) {      // q: fp32 rows, 8 lanes x 16 B per row segment
+        rg_f32x4 cw = *reinterpret_cast<const rg_f32x4*>(p.csq + nw);
+        cw = cw * inv_q;
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt) {
+          float* const ws = ws0 + (mt & (NPATCH - 1)) * (16 * 36);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ws[(kq * 4 + e) * 36 + nt * 16 + r16] = acc[mt][nt][e];
+#pragma unroll
+          for (int ps = 0; ps < 2; ++ps) {
+            const int trow = mt * 16 + ps * 8 + prow;
+            const long mrow = (long)m0 + trow;
+            const rg_f32x4 v = *reinterpret_cast<const rg_f32x4*>(ws + (ps * 8 + prow) * 36 + pc4) * cw;
+            if (trow >= RO || mrow >= p.M) continue;
+            *(__attribute__((address_space(1))) rg_f32x4*)(p.q + mrow * LDQ + nw) = v;
+          }
+        }
+      } else {
+        // k / v: fp16 planes, a lane takes EIGHT columns of a row (16-byte stores per plane: rowblock_kernel)
+        const int prow16 = lane >> 2, pc8 = (lane & 3) * 8;
+        const int nw8 = c * 256 + wave * 32 + pc8;
+        rg_f32x4 cw0 = *reinterpret_cast<const rg_f32x4*>(p.csq + nw8), cw1 = *reinterpret_cast<const rg_f32x4*>(p.csq + nw8 + 4);
+        cw0 = cw0 * (inv_q * sc);      // (powers of two: the same bits as scaling the product)
+        cw1 = cw1 * (inv_q * sc);
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt) {
+          float* const ws = ws0 + (mt & (NPATCH - 1)) * (16 * 36);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ws[(kq * 4 + e) * 36 + nt * 16 + r16] = acc[mt][nt][e];
+          const int trow = mt * 16 + prow16;
+          const long mrow = (long)m0 + trow;
+          const rg_f32x4 v0 = *reinterpret_cast<const rg_f32x4*>(ws + prow16 * 36 + pc8) * cw0;
+          const rg_f32x4 v1 = *reinterpret_cast<const rg_f32x4*>(ws + prow16 * 36 + pc8 + 4) * cw1;
+          if (trow >= RO || mrow >= p.M) continue;
+          const Split2 s0 = split2h_pair(v0[0], v0[1]), s1 = split2h_pair(v0[2], v0[3]);
+          const Split2 s2 = split2h_pair(v1[0], v1[1]), s3 = split2h_pair(v1[2], v1[3]);
+          unsigned short* const o2 = p.kv2 + mrow * LDKV + (nw8 - 512);
+          *(__attribute__((address_space(1))) rg_u32x4*)(o2) = rg_u32x4{s0.h, s1.h, s2.h, s3.h};
+          *(__attribute__((address_space(1))) rg_u32x4*)(o2 + p.kv2_plane) = rg_u32x4{s0.l, s1.l, s2.l, s3.l};
         }
       }
     }

@@ -552,6 +552,45 @@ def test_res_pair_matches_two_launches(monkeypatch):
     assert torch.equal(fused[0], separate[0])
 
 
+def test_res_qkv_matches_separate_launch(monkeypatch):
+    """The first q | k | v of a stage inside the resnet launch that precedes it (rowres_kernel<RT, true>: the following
+    block's LayerNorm1 planes stay in LDS as the operand of a third product, rowblock_kernel's phase C) against its own launch
+    over planes written to HBM (rowgemm_wa_kernel, JV_NO_RES_QKV=1).  The same planes, K order and epilogue expressions: the
+    mels must be EQUAL -- tile heights 5, 2, 4 as in the test above, compact and uniform geometry.  The profiler shows the
+    switch: 13 fused launches per step (the first resnet's input has no measured bound), and only the first stage's q | k | v
+    left as a launch of its own"""
+    import jyutvoice_amd
+    from jyutvoice_amd import synth, engine
+    sd = synth.tts_state_dict(fixed_duration=1.5)
+    keys = ("x", "x_lengths", "lang", "tone", "word_pos", "syllable_pos", "spk_embed")
+    cases = [synth.batch(32, 150), synth.batch(8, 150, first_index=40, lengths=[150 - 11 * i for i in range(8)]),
+             synth.batch(20, 131, first_index=7, lengths=[131 - 3 * i for i in range(20)])]
+
+    def run():
+        tts, _ = jyutvoice_amd.build_default("cuda:0")
+        tts.load_state_dict(sd)
+        mels = [tts.synthesise(*[b[k] for k in keys], None, n_timesteps=2, batched=True)["mel"].cpu() for b in cases]
+        engine.profile_enable(True)
+        try:
+            tts.synthesise(*[cases[0][k] for k in keys], None, n_timesteps=2, batched=True)
+            rep = engine.profile_report()
+        finally:
+            engine.profile_enable(False)
+        return mels, rep
+
+    def count(rep, prefix, tag):
+        return sum(v["launches"] for k, v in rep.items() if k.startswith(prefix) and (tag in k))
+
+    fused, rep_f = run()
+    monkeypatch.setenv("JV_NO_RES_QKV", "1")
+    separate, rep_s = run()
+    assert count(rep_f, "rowres_h3", ",qkv>") == 2 * 13 and count(rep_s, "rowres_h3", ",qkv>") == 0
+    assert count(rep_f, "rowgemm_h3", ",qkv>") == 2 * 1 and count(rep_s, "rowgemm_h3", ",qkv>") == 2 * 14
+    for f, s in zip(fused, separate):
+        assert torch.isfinite(f).all()
+        assert torch.equal(f, s)
+
+
 def test_timestep_embeddings_once_per_solve(monkeypatch):
     """cfm_solve computes the timestep embedding of every Euler step ahead of the loop (three GEMMs of n_timesteps rows) and
     each step copies its row into place; JV_NO_TEMB_PRE=1 computes it inside every step for all 2B (identical) rows, as the

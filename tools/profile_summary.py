@@ -20,9 +20,9 @@ def short(name):
     m = re.search(r"rowblock_kernel<(\d+), (true|false|0|1)(?:, (?:true|false|0|1))?>", name)      # (<RT, QKV, STAG>)
     if m:
         return f"rowblock_h3<{16 * int(m.group(1))}x256{',qkv' if m.group(2) in ('true', '1') else ''}>"
-    m = re.search(r"rowres_kernel<(\d+)>", name)      # a whole resnet in one launch
+    m = re.search(r"rowres_kernel<(\d+)(?:, (\w+))?>", name)      # a whole resnet in one launch (+ the following block's q | k | v)
     if m:
-        return f"rowres_h3<{16 * int(m.group(1))}x256>"
+        return f"rowres_h3<{16 * int(m.group(1))}x256{',qkv' if m.group(2) in ('true', '1') else ''}>"
     m = re.search(r"rowffn_kernel<(\d+)>", name)
     if m:
         return f"rowffn_h3<{16 * int(m.group(1))}x256>"
