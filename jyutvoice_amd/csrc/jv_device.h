@@ -34,6 +34,28 @@ __device__ __forceinline__ float gelu_erf(const float v) {
   return fmaf(0.5f, v + fabsf(v), -w);
 }
 
+// The same chain on TWO values per instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 are full-rate on gfx950: an fma per
+// lane and component is the same IEEE operation, so the results are gelu_erf's bit for bit).  For the fused block's GELU pass,
+// which is pure vector issue with the matrix pipe idle: nine of the chain's fourteen operations are the polynomial.
+typedef float jv_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ jv_f32x2 gelu_erf2(const jv_f32x2 v) {
+  const jv_f32x2 a = {fabsf(v[0]), fabsf(v[1])};
+  const jv_f32x2 u = {fminf(a[0], 6.5f), fminf(a[1], 6.5f)};
+  auto c2 = [](const float c) { return jv_f32x2{c, c}; };
+  jv_f32x2 q = c2(3.9286530295612465e-07f);
+  q = __builtin_elementwise_fma(q, u, c2(-7.801393621775787e-06f));
+  q = __builtin_elementwise_fma(q, u, c2(6.441200821427628e-05f));
+  q = __builtin_elementwise_fma(q, u, c2(-0.00025067193200811744f));
+  q = __builtin_elementwise_fma(q, u, c2(-4.676209937315434e-05f));
+  q = __builtin_elementwise_fma(q, u, c2(0.0069969831965863705f));
+  q = __builtin_elementwise_fma(q, u, c2(-0.0524740107357502f));
+  q = __builtin_elementwise_fma(q, u, c2(-0.45920976996421814f));
+  q = __builtin_elementwise_fma(q, u, c2(-1.151105523109436f));
+  q = __builtin_elementwise_fma(q, u, c2(-1.0f));
+  const jv_f32x2 w = u * jv_f32x2{__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+  return __builtin_elementwise_fma(c2(0.5f), v + a, -w);
+}
+
 // sum over the 64 lanes of a wave, returned in every lane: four DPP butterflies inside each row of 16 lanes, then the four
 // row totals R0..R3 combined as (R0 + R1) + (R2 + R3) with gfx950's row / half exchanges (v_permlane16_swap: rows 1 and 3 of
 // the first operand trade places with rows 0 and 2 of the second; v_permlane32_swap: the same for the two halves) -- all

@@ -585,8 +585,18 @@ __global__ __launch_bounds__(512, 2) void rowblock_kernel(const RowBlockArgs p) 
       for (int nt = 0; nt < 2; ++nt) {
         const int slot = (2 * nt + (r16 >> 3)) ^ key;
         float g4[4];
+#ifdef JV_GELU_SCALAR      // (A/B builds: one value per instruction, as rowffn_kernel does)
 #pragma unroll
         for (int e = 0; e < 4; ++e) g4[e] = JV_ABLATE(p, 1) ? acc1[mt][nt][e] : gelu_erf(acc1[mt][nt][e] * csl[nt] + bl[nt]) * p.h_scale;
+#else
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {      // two rows per instruction (jv_device.h gelu_erf2: the same operations, packed)
+          const jv_f32x2 x2 = jv_f32x2{acc1[mt][nt][e], acc1[mt][nt][e + 1]} * jv_f32x2{csl[nt], csl[nt]} + jv_f32x2{bl[nt], bl[nt]};
+          const jv_f32x2 g2 = gelu_erf2(x2) * jv_f32x2{p.h_scale, p.h_scale};
+          g4[e] = JV_ABLATE(p, 1) ? acc1[mt][nt][e] : g2[0];
+          g4[e + 1] = JV_ABLATE(p, 1) ? acc1[mt][nt][e + 1] : g2[1];
+        }
+#endif
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
           const Split2 sp = JV_ABLATE(p, 1) ? Split2{__float_as_uint(g4[e]), __float_as_uint(g4[e + 1])}

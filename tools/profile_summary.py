@@ -72,21 +72,29 @@ def short(name):
 
 
 print(f"# rocprofv3 summary ({os.path.basename(out)})\n")
-stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
+def newest(pattern):      # (a directory merged back from several GPU calls holds every call's files: the last run's count)
+    return sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)[-1:]
+
+
+stats = newest(os.path.join(out, "trace", "**", "*kernel_stats.csv"))
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     print("## kernel-trace --stats (bench.py --steps 3 --warmup 1; all 4 passes of the path included)\n")
     print("| kernel | calls | total ms | avg us | % |")
     print("|---|---|---|---|---|")
-    for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:22]:
-        print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | "
-              f"{float(r['AverageNs']) / 1e3:.2f} | {100 * float(r['TotalDurationNs']) / tot:.1f} |")
+    by_name = defaultdict(lambda: [0, 0.0])      # template instances that share a short name (kernel sizes of a pair kernel, ...) are one row
+    for r in rows:
+        a = by_name[short(r["Name"])]
+        a[0] += int(r["Calls"])
+        a[1] += float(r["TotalDurationNs"])
+    for k, (n, t) in sorted(by_name.items(), key=lambda kv: -kv[1][1])[:22]:
+        print(f"| {k} | {n} | {t / 1e6:.2f} | {t / n / 1e3:.2f} | {100 * t / tot:.1f} |")
     print(f"\ntotal kernel time {tot / 1e6:.1f} ms\n")
 
 traffic = defaultdict(dict)
 for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    files = glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True)
+    files = newest(os.path.join(out, tag, "**", "*counter_collection.csv"))
     if not files:
         continue
     agg = defaultdict(lambda: [0, 0.0])
