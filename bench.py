@@ -445,7 +445,8 @@ def main():
                                  "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                  "launches_per_pass": cs["launches"] // prof_steps,
                                  "alg_tflops": round(cs["flops"] / (cs["ms"] * 1e-3) / 1e12, 2)}
-            if cs_alone and cs_alone["ms"] > 0:
+            fused_qkv = any(k.startswith("rowres_h3") and k.endswith(",qkv>") for k in kern)      # (not in the column-split regime of few row tiles: C2)
+            if cs_alone and cs_alone["ms"] > 0 and fused_qkv:
                 # (the numbers above are the group as the default build launches it: q | k | v of 13 stages inside; these are the stack alone)
                 one = n_steps * (96064.0 * 2 * (valid_frames if args.ragged else B * T) + 29.5e6)
                 g1 = one / (cs_alone["ms"] * 1e-3) / 1e9
