@@ -57,6 +57,7 @@ def test_throughput_is_monotone_and_every_regime_matches_the_oracle(tts_sd, nois
                 torch.cuda.synchronize()
                 times.append(time.perf_counter() - t0)
             rate[B] = B * T / sorted(times)[1]
+        print("regime rates (frames/s):", {b: round(r) for b, r in rate.items()})      # (pytest -s / -rP shows it)
         best = 0.0
         for B in BATCHES:
             assert rate[B] >= 0.85 * best, (f"throughput dips at {B} utterances: {rate[B]:.0f} frames/s after {best:.0f}",
