@@ -151,3 +151,43 @@ def test_tokens_json_raw_lists_get_their_blanks():
     assert out["x"].tolist() == [[0, 12, 0, 96, 0]] and out["x_lengths"].tolist() == [5] and out["lang"].tolist() == [[0, 1, 0, 3, 0]]
     with pytest.raises(ValueError):
         load_tokens_json({"interspersed": False, "x": [], "lang": [], "tone": [], "word_pos": [], "syllable_pos": []})
+
+
+def test_profile_summary_names_match_the_library_profiler():
+    """tools/profile_summary.py maps rocprofv3's demangled kernel names onto the names the in-library profiler gives the same
+    launches (bench.py joins the PMC traffic file to its own kernel table by that name, and quotes `roofline.traffic` only on a
+    match): every kernel of the headline path, in the spelling rocprofv3 prints.  A template parameter added to a kernel
+    without this mapping following (round 4: the pair kernel's size, the whole-resnet launch's q | k | v) silently drops the
+    traffic figure from the bench line"""
+    import importlib.util
+    import os
+    import sys
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if REPO not in sys.path:
+        sys.path.insert(0, REPO)
+    spec = importlib.util.spec_from_file_location("profile_summary", os.path.join(REPO, "tools", "profile_summary.py"))
+    ps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ps)
+    want = {
+        "void jv::rowblock_kernel<5, true, false>(jv::RowBlockArgs)": "rowblock_h3<80x256,qkv>",
+        "void jv::rowblock_kernel<4, false, false>(jv::RowBlockArgs)": "rowblock_h3<64x256>",
+        "void jv::rowres_kernel<5, true>(jv::RowResArgs)": "rowres_h3<80x256,qkv>",
+        "void jv::rowres_kernel<3, false>(jv::RowResArgs)": "rowres_h3<48x256>",
+        "void jv::rowconv_wd_kernel<5, false>(jv::RowConvArgs)": "rowconv_h3<80x256,k3>",
+        "void jv::rowconv_wd_kernel<5, true>(jv::RowConvArgs)": "rowconv_h3<80x256,k3+res>",
+        "void jv::rowgemm_wa_kernel<5, 4>(jv::RowGemmArgs)": "rowgemm_h3<80x256,qkv>",
+        "void jv::hiftpair_kernel<64, 2, 11>(jv::HiftPairArgs)": "hiftpair_h3<160x64,snake>",
+        "void jv::hiftpair_kernel<128, 2, 3>(jv::HiftPairArgs)": "hiftpair_h3<160x128,snake>",
+        "void jv::hiftconv_kernel<256, 1>(jv::HiftConvArgs)": "hiftconv_h3<80x256,snake>",
+        "void jv::(anonymous namespace)::attn64_s_kernel<5, 2, 0>(jv::AttnArgs)": "attn64_s<320 q>",
+    }
+    for raw, name in want.items():
+        assert ps.short(raw) == name, (raw, ps.short(raw))
+    # ... and every name the committed PMC pass holds for the dominant kernels is one bench.py's peak table knows
+    import json
+    import bench
+    pmc = json.load(open(os.path.join(REPO, "profiles", "r04_pmc_traffic.json")))
+    for k in ("rowblock_h3<80x256,qkv>", "rowres_h3<80x256,qkv>", "attn64_s<320 q>", "hiftpair_h3<160x64,snake>"):
+        assert k in pmc["kernels"], k
+        peak, _ = bench.kernel_peak(k)
+        assert 800 < peak < 900, (k, peak)      # the fp16x3 ceiling: dense fp16 MFMA / 3

@@ -8,8 +8,6 @@ import re
 import sys
 from collections import defaultdict
 
-out = sys.argv[1]
-
 
 def short(name):
     """rocprofv3 kernel name -> the name bench.py's in-library profiler gives the same launches"""
@@ -71,60 +69,65 @@ def short(name):
     return (m.group(1) if m else name)[:48]
 
 
-print(f"# rocprofv3 summary ({os.path.basename(out)})\n")
-def newest(pattern):      # (a directory merged back from several GPU calls holds every call's files: the last run's count)
-    return sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)[-1:]
+def main(out):
+    print(f"# rocprofv3 summary ({os.path.basename(out)})\n")
+    def newest(pattern):      # (a directory merged back from several GPU calls holds every call's files: the last run's count)
+        return sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)[-1:]
 
 
-stats = newest(os.path.join(out, "trace", "**", "*kernel_stats.csv"))
-if stats:
-    rows = list(csv.DictReader(open(stats[0])))
-    tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    print("## kernel-trace --stats (bench.py --steps 3 --warmup 1; all 4 passes of the path included)\n")
-    print("| kernel | calls | total ms | avg us | % |")
-    print("|---|---|---|---|---|")
-    by_name = defaultdict(lambda: [0, 0.0])      # template instances that share a short name (kernel sizes of a pair kernel, ...) are one row
-    for r in rows:
-        a = by_name[short(r["Name"])]
-        a[0] += int(r["Calls"])
-        a[1] += float(r["TotalDurationNs"])
-    for k, (n, t) in sorted(by_name.items(), key=lambda kv: -kv[1][1])[:22]:
-        print(f"| {k} | {n} | {t / 1e6:.2f} | {t / n / 1e3:.2f} | {100 * t / tot:.1f} |")
-    print(f"\ntotal kernel time {tot / 1e6:.1f} ms\n")
+    stats = newest(os.path.join(out, "trace", "**", "*kernel_stats.csv"))
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        print("## kernel-trace --stats (bench.py --steps 3 --warmup 1; all 4 passes of the path included)\n")
+        print("| kernel | calls | total ms | avg us | % |")
+        print("|---|---|---|---|---|")
+        by_name = defaultdict(lambda: [0, 0.0])      # template instances that share a short name (kernel sizes of a pair kernel, ...) are one row
+        for r in rows:
+            a = by_name[short(r["Name"])]
+            a[0] += int(r["Calls"])
+            a[1] += float(r["TotalDurationNs"])
+        for k, (n, t) in sorted(by_name.items(), key=lambda kv: -kv[1][1])[:22]:
+            print(f"| {k} | {n} | {t / 1e6:.2f} | {t / n / 1e3:.2f} | {100 * t / tot:.1f} |")
+        print(f"\ntotal kernel time {tot / 1e6:.1f} ms\n")
 
-traffic = defaultdict(dict)
-for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    files = newest(os.path.join(out, tag, "**", "*counter_collection.csv"))
-    if not files:
-        continue
-    agg = defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(files[0])):
-        if r.get("Counter_Name") != counter:
+    traffic = defaultdict(dict)
+    for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        files = newest(os.path.join(out, tag, "**", "*counter_collection.csv"))
+        if not files:
             continue
-        a = agg[short(r["Kernel_Name"])]
-        a[0] += 1
-        a[1] += float(r["Counter_Value"])
-    mult = 2.0 if counter == "FETCH_SIZE" else 1.0
-    print(f"## --pmc {counter} (1 step; KiB per dispatch{', x2 gfx950 correction applied' if mult == 2 else ''})\n")
-    print("| kernel | dispatches | MB per launch |")
-    print("|---|---|---|")
-    for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
-        print(f"| {k} | {n} | {mult * v * 1024 / n / 1e6:.2f} |")
-    print()
-    for k, (n, v) in agg.items():
-        traffic[k]["fetch_bytes" if counter == "FETCH_SIZE" else "write_bytes"] = round(mult * v * 1024 / n)
+        agg = defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(files[0])):
+            if r.get("Counter_Name") != counter:
+                continue
+            a = agg[short(r["Kernel_Name"])]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+        mult = 2.0 if counter == "FETCH_SIZE" else 1.0
+        print(f"## --pmc {counter} (1 step; KiB per dispatch{', x2 gfx950 correction applied' if mult == 2 else ''})\n")
+        print("| kernel | dispatches | MB per launch |")
+        print("|---|---|---|")
+        for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
+            print(f"| {k} | {n} | {mult * v * 1024 / n / 1e6:.2f} |")
+        print()
+        for k, (n, v) in agg.items():
+            traffic[k]["fetch_bytes" if counter == "FETCH_SIZE" else "write_bytes"] = round(mult * v * 1024 / n)
 
-if traffic:   # per-launch HBM bytes by kernel, read back by bench.py for roofline.traffic
-    import json
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from jyutvoice_amd.build import source_hash
-    with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
-        extra = os.environ.get("JV_PROFILE_ARGS", "").split()      # e.g. --workload c2 --batch 8 --tokens 256 (tools/profile.sh)
-        def arg(name, default):
-            return extra[extra.index(name) + 1] if name in extra else default
-        json.dump({"csrc_sha16": source_hash(),      # bench.py quotes these figures only for the build they were measured on
-                   "shape": {"workload": arg("--workload", "c3"), "batch": int(arg("--batch", 32)), "tokens": int(arg("--tokens", 150)),
-                             "timesteps": int(arg("--timesteps", 10))},
-                   "source": f"tools/profile.sh {os.path.basename(out)}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE, "
-                             f"separate passes over bench.py --steps 1 {' '.join(extra)}, bytes per launch",
-                   "kernels": traffic}, fh, indent=1, sort_keys=True)
+    if traffic:   # per-launch HBM bytes by kernel, read back by bench.py for roofline.traffic
+        import json
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from jyutvoice_amd.build import source_hash
+        with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
+            extra = os.environ.get("JV_PROFILE_ARGS", "").split()      # e.g. --workload c2 --batch 8 --tokens 256 (tools/profile.sh)
+            def arg(name, default):
+                return extra[extra.index(name) + 1] if name in extra else default
+            json.dump({"csrc_sha16": source_hash(),      # bench.py quotes these figures only for the build they were measured on
+                       "shape": {"workload": arg("--workload", "c3"), "batch": int(arg("--batch", 32)), "tokens": int(arg("--tokens", 150)),
+                                 "timesteps": int(arg("--timesteps", 10))},
+                       "source": f"tools/profile.sh {os.path.basename(out)}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE, "
+                                 f"separate passes over bench.py --steps 1 {' '.join(extra)}, bytes per launch",
+                       "kernels": traffic}, fh, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
