@@ -9,7 +9,9 @@
 //   NB     buffers per wave (2, 3, 4)
 //   SPLIT  1: a buffer's first half is requested right behind the first column block's MFMAs, the second half at the end
 //             of the step (the kernels' pattern); 0: all four loads at the end of the step
-//   LONE   1: waves 4..7 leave at once -- one wave per SIMD, the staggered schedule's situation
+//   LONE   1: waves 4..7 leave at once -- one wave per SIMD; 2: waves 4..7 run independent v_fma_f32 with vector-register
+//             operands for as long as the MFMA waves run (the staggered schedule's situation: the other half in its GELU pass);
+//             3: the same with the fma's operands in SGPRs
 // Output: median over all waves of (s_memtime at loop end - at loop start) / steps, and the kernel's time by HIP events.
 //   hipcc --offload-arch=gfx950 -O2 tools/probes/wfrag_lookahead.hip -o /tmp/wfrag_lookahead && /tmp/wfrag_lookahead
 #include <hip/hip_runtime.h>
@@ -49,7 +51,32 @@ __global__ __launch_bounds__(512, 2) void probe(const unsigned short* __restrict
   const int r16 = lane & 15, kq = lane >> 4;
   for (int i = tid; i < 8 * STAGE / 4; i += 512) reinterpret_cast<unsigned*>(lds)[i] = 0x3c003c00u + (i & 255);      // halves near 1.0
   __syncthreads();
-  if (lone && wave >= 4) return;
+  if (lone == 1 && wave >= 4) return;
+  if (lone >= 2 && wave >= 4) {
+    // the SIMD's other wave does vector work for as long as the MFMA wave runs (the staggered schedule's GELU pass):
+    // lone == 2: sixteen independent fp32 fmas per iteration (two register operands + one accumulator each);
+    // lone == 3: the same from four operands held in SGPRs (no vector-register reads besides the accumulator)
+    float x[16];
+    for (int i = 0; i < 16; ++i) x[i] = lane * 1e-3f + i;
+    float c0 = 1.0001f, c1 = 0.5f;
+    asm volatile("" : "+v"(c0), "+v"(c1));
+    float k0 = 1.0001f, k1 = 0.5f;
+    asm volatile("" : "+s"(k0), "+s"(k1));
+#pragma unroll 1
+    for (int it = 0; it < 5200; ++it) {
+      if (lone == 2) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(c0), "v"(c1));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[i]) : "s"(k0));
+      }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += x[i];
+    if (s == 12345.678f) sink[1] = s;
+    return;
+  }
   const unsigned short* wb[2][2];
   for (int nt = 0; nt < 2; ++nt)
     for (int pl = 0; pl < 2; ++pl) wb[nt][pl] = W + (long)pl * plane + (long)(wave * 2 + nt) * 512 + lane * 8;
@@ -173,7 +200,7 @@ int main() {
   float* sink;
   hipMalloc(&W, sizeof(unsigned short) * 2 * plane);
   hipMalloc(&t, sizeof(unsigned long long) * 256 * 8);
-  hipMalloc(&sink, 4);
+  hipMalloc(&sink, 8);
   std::vector<unsigned short> hw(2 * plane);
   for (size_t i = 0; i < hw.size(); ++i) hw[i] = 0x3800 + (i % 97);      // halves near 0.5
   hipMemcpy(W, hw.data(), sizeof(unsigned short) * hw.size(), hipMemcpyHostToDevice);
@@ -183,6 +210,10 @@ int main() {
     run<3, 1>(W, plane, t, sink, lone);
     run<3, 0>(W, plane, t, sink, lone);
     run<4, 1>(W, plane, t, sink, lone);
+    run<4, 0>(W, plane, t, sink, lone);
+  }
+  for (int lone = 2; lone < 4; ++lone) {
+    run<2, 1>(W, plane, t, sink, lone);
     run<4, 0>(W, plane, t, sink, lone);
   }
   printf("(30 MFMAs of 16 cycles per step and wave: 480 cycles of issue; two waves per SIMD: 960 per step pair)\n");
