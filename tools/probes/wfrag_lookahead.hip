@@ -11,7 +11,7 @@
 //             of the step (the kernels' pattern); 0: all four loads at the end of the step
 //   LONE   1: waves 4..7 leave at once -- one wave per SIMD; 2: waves 4..7 run independent v_fma_f32 with vector-register
 //             operands for as long as the MFMA waves run (the staggered schedule's situation: the other half in its GELU pass);
-//             3: the same with the fma's operands in SGPRs
+//             3: the same with the fma's operands in SGPRs; 4 / 5: 2 + two / eight dword LDS stores per 16 fmas; 6: 2 + two v_exp_f32
 // Output: median over all waves of (s_memtime at loop end - at loop start) / steps, and the kernel's time by HIP events.
 //   hipcc --offload-arch=gfx950 -O2 tools/probes/wfrag_lookahead.hip -o /tmp/wfrag_lookahead && /tmp/wfrag_lookahead
 #include <hip/hip_runtime.h>
@@ -64,12 +64,23 @@ __global__ __launch_bounds__(512, 2) void probe(const unsigned short* __restrict
     asm volatile("" : "+s"(k0), "+s"(k1));
 #pragma unroll 1
     for (int it = 0; it < 5200; ++it) {
-      if (lone == 2) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(c0), "v"(c1));
-      } else {
+      if (lone == 3) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[i]) : "s"(k0));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(c0), "v"(c1));
+      }
+      // lone == 4: + two dword LDS stores per 16 fmas (the GELU pass's ratio: the hidden tile's planes leave as dwords);
+      // lone == 5: + eight; lone == 6: + two v_exp_f32 (quarter rate)
+      if (lone == 4 || lone == 5) {
+        unsigned* const dst = reinterpret_cast<unsigned*>(lds + 8 * STAGE) + (wave - 4) * 4096 + ((it & 15) * 256) + lane;
+        const int n = lone == 4 ? 2 : 8;
+        for (int i = 0; i < n; ++i) dst[i * 64] = __float_as_uint(x[i]);
+      }
+      if (lone == 6) {
+        asm volatile("v_exp_f32 %0, %0" : "+v"(x[0]));
+        asm volatile("v_exp_f32 %0, %0" : "+v"(x[1]));
       }
     }
     float s = 0.f;
@@ -212,7 +223,7 @@ int main() {
     run<4, 1>(W, plane, t, sink, lone);
     run<4, 0>(W, plane, t, sink, lone);
   }
-  for (int lone = 2; lone < 4; ++lone) {
+  for (int lone = 2; lone < 7; ++lone) {
     run<2, 1>(W, plane, t, sink, lone);
     run<4, 0>(W, plane, t, sink, lone);
   }
